@@ -1,0 +1,139 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * Deterministic f32 math + Philox4x32-10, restated on the CPU so that the
+ * oracle's tree search reproduces the HIP engine's floating-point decisions
+ * bit for bit: every operation below is an IEEE-754 basic operation (add, mul,
+ * div, sqrt, fma) in a fixed order, so gcc (-ffp-contract=off) and hipcc
+ * (-ffp-contract=off) produce identical bits.  The product's own copy lives in
+ * ataxxzero_amd/csrc/detmath.cuh; the two are kept in step by
+ * tests/test_detmath_gpu.py.
+ *
+ * These functions replace libm's exp/log/gamma sampling that the reference
+ * uses in double precision (cpp/self_play_client.cpp:208-218 softmax,
+ * :250-266 std::gamma_distribution); the reference's RNG is an unseeded,
+ * unlocked global engine (:39-40), so there is no reference bit pattern to
+ * match — only the distributions.
+ */
+#ifndef ORACLE_DETMATH_H
+#define ORACLE_DETMATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline float orc_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t orc_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* exp(x), |rel err| ~ 2e-7; 0 below -87, clamped above 88. */
+static inline float orc_det_expf(float x)
+{
+    if (!(x >= -87.0f))
+        return 0.0f;
+    if (x > 88.0f)
+        x = 88.0f;
+    float t = x * 1.44269504f;
+    float n = (t + 12582912.0f) - 12582912.0f; /* round to nearest integer */
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float rr = r * r;
+    float y = __builtin_fmaf(p, rr, r);
+    y = y + 1.0f;
+    int32_t ni = (int32_t)n;
+    return y * orc_u2f((uint32_t)(ni + 127) << 23);
+}
+
+/* log(x) for normal x > 0, |rel err| ~ 2e-7. */
+static inline float orc_det_logf(float x)
+{
+    if (!(x >= 1.17549435e-38f))
+        return -87.33654475f;
+    uint32_t b = orc_f2u(x);
+    int32_t e = (int32_t)((b >> 23) & 255u) - 126;
+    float m = orc_u2f((b & 0x007FFFFFu) | 0x3F000000u); /* [0.5, 1) */
+    if (m < 0.70710678f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, m, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, m, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, m, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, m, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, m, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, m, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, m, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, m, 3.3333331174e-1f);
+    float y = (m * z) * p;
+    float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(z, -0.5f, y);
+    float r = m + y;
+    return __builtin_fmaf(fe, 0.693359375f, r);
+}
+
+/* Philox4x32-10 (Salmon et al. 2011). */
+static inline void orc_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                              uint32_t c3, uint32_t out[4])
+{
+    for (int round = 0; round < 10; round++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#define ORC_STREAM_SAMPLE 1u
+#define ORC_STREAM_RANDOM_PLAY 2u
+#define ORC_STREAM_GAMMA 0x10000u
+
+/* Gamma(alpha, 1) for alpha < 1: Marsaglia-Tsang on alpha + 1 with a polar
+ * normal, boosted by U^(1/alpha).  One Philox block per attempt, keyed
+ * (uid, ply, ORC_STREAM_GAMMA + edge, attempt). */
+static inline float orc_det_gamma(float alpha, uint32_t k0, uint32_t k1, uint32_t uid, uint32_t ply,
+                                  uint32_t edge)
+{
+    float d = (alpha + 1.0f) - 0.333333343f;
+    float c = 1.0f / sqrtf(9.0f * d);
+    for (uint32_t attempt = 0; attempt < 64u; attempt++) {
+        uint32_t r[4];
+        orc_philox(k0, k1, uid, ply, ORC_STREAM_GAMMA + edge, attempt, r);
+        float u1 = (float)(r[0] >> 8) * 1.1920929e-7f - 1.0f; /* [-1, 1) */
+        float u2 = (float)(r[1] >> 8) * 1.1920929e-7f - 1.0f;
+        float s = u1 * u1 + u2 * u2;
+        if (!(s < 1.0f) || s == 0.0f)
+            continue;
+        float x = u1 * sqrtf((-2.0f * orc_det_logf(s)) / s);
+        float v = 1.0f + c * x;
+        if (!(v > 0.0f))
+            continue;
+        v = (v * v) * v;
+        float U = (float)((r[2] >> 8) + 1u) * 5.9604645e-8f; /* (0, 1] */
+        float lhs = orc_det_logf(U);
+        float rhs = ((0.5f * x) * x + d) - d * v + d * orc_det_logf(v);
+        if (!(lhs < rhs))
+            continue;
+        float U2 = (float)((r[3] >> 8) + 1u) * 5.9604645e-8f;
+        float boost = orc_det_expf(orc_det_logf(U2) / alpha);
+        return (d * v) * boost;
+    }
+    return 0.0f;
+}
+
+#endif

@@ -1,0 +1,101 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * Sequential CPU restatement of the reference's batched self-play search
+ * (cpp/self_play_client.cpp:153-582): PUCT select (:310-366,:386-417), expand +
+ * evaluate + backup (:419-473), visit-proportional move sampling (:495-506),
+ * tree reuse on play (:475-492), Dirichlet root noise (:250-271), game records
+ * (:508-582).  The reference is irreproducible by construction (unseeded shared
+ * RNG, hash-order tie-breaks: SURVEY.md §7 "hard parts"), so this oracle fixes
+ * the two free choices — ties go to the LAST maximal edge in movegen order
+ * (the reference's `>=`, :354) and all randomness is Philox keyed by
+ * (seed, game uid, ply, stream) — and the HIP engine must then match it bit
+ * for bit on every integer and every f32 it stores.
+ *
+ * Used by tests/ as the checker and by bench.py's cpu_baseline leg only.
+ */
+#ifndef MCTS_ORACLE_H
+#define MCTS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t games;            /* concurrent game slots */
+    int32_t visits;           /* root visit threshold per move (global_visits, :46,:522) */
+    int32_t max_plies;        /* maximum_game_plies = 400 (:34) */
+    int32_t edges_per_node;   /* edge arena = node_cap * edges_per_node */
+    float c_puct;             /* exploration_parameter = 1.0 (:31) */
+    float dirichlet_alpha;    /* 0.15 (:32) */
+    float dirichlet_weight;   /* 0.25 (:33) */
+    int32_t start_turn;
+    uint64_t seed;
+    uint64_t start_x, start_o, blockers; /* STARTING_GAME_POSITION (:23) */
+} orc_config;
+
+enum { ORC_LEAF_NONE = 0, ORC_LEAF_EVAL = 1, ORC_LEAF_TERMINAL = 2, ORC_LEAF_ROOT = 3 };
+enum { ORC_PHASE_ROOT_EVAL = 0, ORC_PHASE_SEARCH = 1 };
+
+/* per-game scalar state, same field order as the HIP engine's snapshot */
+typedef struct {
+    int32_t phase, arena, n_nodes, n_edges, ply, root_visits, leaf_kind, leaf_node, path_len;
+    uint32_t uid;
+} orc_game_state;
+
+enum {
+    ORC_STAT_STEPS = 0,      /* MCTS steps (node-evals incl. terminal re-hits) */
+    ORC_STAT_NN_EVALS,       /* leaves sent to the evaluator (incl. root refresh) */
+    ORC_STAT_LEVELS,         /* L: levels descended */
+    ORC_STAT_CHILDREN,       /* C: children scanned */
+    ORC_STAT_NEW_MOVES,      /* M: legal moves of new nodes */
+    ORC_STAT_PLIES,
+    ORC_STAT_GAMES,
+    ORC_STAT_DROPPED,
+    ORC_STAT_EDGE_OVERFLOW,
+    ORC_STAT_REROOT_NODES,
+    ORC_STAT_REROOT_EDGES,
+    ORC_STAT_COUNT = 16
+};
+
+typedef struct orc_engine orc_engine;
+
+orc_engine *orc_engine_create(const orc_config *cfg);
+void orc_engine_destroy(orc_engine *e);
+int orc_engine_node_cap(const orc_engine *e);
+int orc_engine_edge_cap(const orc_engine *e);
+
+/* phase 1 of an iteration: select/expand in every game; returns #leaves needing
+ * the evaluator.  need_eval[g] (optional) = 1 for those games. */
+int orc_engine_select(orc_engine *e, int32_t *need_eval);
+/* (mover, opponent) bitboards of every game's leaf, [G][2] */
+void orc_engine_leaf_boards(const orc_engine *e, uint64_t *out);
+/* reference feature rows (cpp/self_play_client.cpp:174-202) for game g's leaf */
+void orc_engine_leaf_features(const orc_engine *e, int g, float *out196);
+/* phase 2: priors / backup / ply advance. logits [G][833], values [G], indexed by game */
+void orc_engine_backup(orc_engine *e, const float *logits, const float *values);
+
+void orc_engine_game_state(const orc_engine *e, int g, orc_game_state *out);
+/* arena dump of game g: boards [n][2] u64, info [n][4] u32, edges [m][4] u32, moves [m] u16 */
+void orc_engine_tree(const orc_engine *e, int g, uint64_t *boards, uint32_t *info, uint32_t *edges,
+                     uint16_t *moves);
+void orc_engine_stats(const orc_engine *e, uint64_t *out /* ORC_STAT_COUNT */);
+
+/* finished games, oldest first. Record = int32 header {slot, uid, plies, result}
+ * then per ply {x u64, o u64, move u16, ndist u16, pad u32, ndist * u32 (move | n << 16)}.
+ * Returns bytes written (0 when none pending or cap too small for the next game). */
+int64_t orc_engine_pop_game(orc_engine *e, uint8_t *buf, int64_t cap);
+int orc_engine_pending_games(const orc_engine *e);
+
+/* detmath probes for tests */
+float orc_probe_expf(float x);
+float orc_probe_logf(float x);
+float orc_probe_gamma(float alpha, uint64_t seed, uint32_t uid, uint32_t ply, uint32_t edge);
+void orc_probe_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
