@@ -1,0 +1,1040 @@
+// Batched MCTS self-play engine for gfx950: thousands of concurrent search trees
+// resident in HBM as structure-of-arrays, one wavefront per game.
+//
+// Replaces the worker threads of the reference's cpp/self_play_client.cpp
+// (file:line under /root/reference):
+//   k_select   PUCT descent + expansion      MCTS::select_principal_variation :386-417,
+//                                            MCTSNode::select_action :333-366,
+//                                            total_action_score :310-324, step() :419-447
+//   k_backup   priors, root noise, backup    Evaluations::populate :204-271, step() :449-459
+//   k_advance  sample, record, re-root       sample_proportionally_to_visits :495-506,
+//                                            generate_game :526-578, MCTS::play :475-492
+// One search iteration = k_select -> k_compact -> (net) -> k_backup -> k_advance;
+// each game contributes exactly one leaf per iteration, so the per-iteration
+// evaluation batch is the number of concurrent games.
+//
+// HBM layout (per game, two ping-pong arenas so re-rooting compacts by copying):
+//   node_board [2][G][node_cap]  16 B  x stones | turn<<63, o stones
+//   node_info  [2][G][node_cap]  16 B  first_edge, n_edges | result<<16, -, terminal value
+//   edge       [2][G][edge_cap]  16 B  prior f32, visits u32, total score f32, child u32
+//   edge_move  [2][G][edge_cap]   2 B  from | to<<8
+// A node's children are one contiguous edge range, so PUCT reads them with a
+// single coalesced 16-byte-per-lane load; children are bump-allocated by the one
+// wave that owns the game (no atomics inside a tree).
+//
+// Determinism contract: given the same config and the same evaluator outputs the
+// engine reproduces oracle/mcts_oracle.c bit for bit (ties -> last maximal edge,
+// Philox-keyed randomness, fixed f32 operation order; compiled -ffp-contract=off).
+#include <algorithm>
+
+#include "azh_device.cuh"
+#include "azh_host.h"
+
+namespace azh {
+
+constexpr int REC_HDR_WORDS = 8;
+constexpr int REC_MAXD = 256;
+constexpr int REC_STRIDE_WORDS = REC_HDR_WORDS + REC_MAXD;
+constexpr u32 RING_MAGIC = 0x415A4847u;  // "AZHG"
+constexpr int NSTAT = AZH_STAT_COUNT;
+
+struct EngineParams {
+    int G, visits, node_cap, edge_cap, path_cap, max_plies;
+    float c_puct, alpha, noise_w;
+    u32 k0, k1;
+    u64 start_x, start_o, blockers;
+    int start_turn;
+    azh_game_state *gs;
+    int *force;
+    int *path;
+    ulonglong2 *node_board;
+    uint4 *node_info;
+    uint4 *edge;
+    u16 *edge_move;
+    ulonglong2 *leaf_board;
+    int *need_eval;
+    int *leaf_list;
+    int *leaf_count;
+    float *logits;
+    float *values;
+    u32 *rec;
+    u32 *ring;
+    u64 ring_cap_words;
+    u64 *ring_head;
+    u64 *stats;
+};
+
+struct Arena {
+    ulonglong2 *nb;
+    uint4 *ni;
+    uint4 *ed;
+    u16 *em;
+};
+
+__device__ inline Arena arena_of(const EngineParams &P, int a, int g)
+{
+    const size_t slot = (size_t)a * P.G + g;
+    Arena A;
+    A.nb = P.node_board + slot * P.node_cap;
+    A.ni = P.node_info + slot * P.node_cap;
+    A.ed = P.edge + slot * P.edge_cap;
+    A.em = P.edge_move + slot * P.edge_cap;
+    return A;
+}
+
+__device__ inline void add_stat(const EngineParams &P, int g, int k, u64 v)
+{
+    if (v)
+        P.stats[(size_t)g * NSTAT + k] += v;
+}
+
+// Fresh tree at the start position in arena 0 (generate_game :510-512,
+// MCTS::init_from_scratch :380-383).  Wave-cooperative; s_moves is LDS scratch.
+__device__ inline void init_game(const EngineParams &P, int g, u32 uid, azh_game_state &s, u16 *s_moves)
+{
+    const int lane = lane_id();
+    Arena A = arena_of(P, 0, g);
+    Board b;
+    b.x = P.start_x;
+    b.o = P.start_o;
+    b.turn = P.start_turn;
+    int res;
+    const int M = wave_movegen(b, P.blockers, s_moves, &res);
+    __syncthreads();
+    for (int j = lane; j < M; j += WAVE) {
+        A.ed[j] = make_uint4(0u, 0u, 0u, NONE);
+        A.em[j] = s_moves[j];
+    }
+    if (lane == 0) {
+        A.nb[0] = make_ulonglong2(pack_word0(b), b.o);
+        A.ni[0] = make_uint4(0u, (u32)M | ((u32)res << 16), 0u, 0u);
+        P.force[g] = 0;
+    }
+    __syncthreads();
+    s.phase = 0;
+    s.arena = 0;
+    s.n_nodes = 1;
+    s.n_edges = M;
+    s.ply = 0;
+    s.root_visits = 0;
+    s.leaf_kind = AZH_LEAF_NONE;
+    s.leaf_node = 0;
+    s.path_len = 0;
+    s.uid = uid;
+}
+
+__global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
+{
+    __shared__ u16 s_moves[MAX_MOVES];
+    const int g = blockIdx.x;
+    azh_game_state s;
+    init_game(P, g, (u32)g, s, s_moves);
+    if (threadIdx.x == 0)
+        P.gs[g] = s;
+    for (int k = threadIdx.x; k < NSTAT; k += WAVE)
+        P.stats[(size_t)g * NSTAT + k] = 0;
+}
+
+// ------------------------------------------------------------------ select + expand
+
+__global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
+{
+    __shared__ u16 s_moves[MAX_MOVES];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    azh_game_state s = P.gs[g];
+    Arena A = arena_of(P, s.arena, g);
+    int *path = P.path + (size_t)g * P.path_cap;
+
+    int kind = AZH_LEAF_NONE, leaf_node = 0, depth = 0, over = 0;
+    u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0;
+    u64 leaf_mover = 0, leaf_opp = 0;
+
+    if (s.phase == 0) {
+        // the root's priors are (re)computed with noise (:380-383, :485-490)
+        kind = AZH_LEAF_ROOT;
+        st_evals = 1;
+        const ulonglong2 w = A.nb[0];
+        const Board b = unpack_board(w.x, w.y);
+        leaf_mover = b.turn ? b.o : b.x;
+        leaf_opp = b.turn ? b.x : b.o;
+    } else {
+        st_steps = 1;
+        u32 node = 0;
+        for (;;) {
+            const uint4 info = A.ni[node];
+            const u32 first = info.x;
+            const int M = (int)(info.y & 0xFFFFu);
+            const int result = (int)(info.y >> 16);
+            if (result != 0 || M == 0) {
+                kind = AZH_LEAF_TERMINAL;  // select_action -> NO_MOVE (:336-340)
+                leaf_node = (int)node;
+                break;
+            }
+            st_levels += 1;
+            st_children += (u64)M;
+            const int rounds = (M + 63) >> 6;
+            uint4 ev[4];
+            u32 nsum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ev[k] = make_uint4(0u, 0u, 0u, NONE);
+                const int j = lane + 64 * k;
+                if (k < rounds && j < M) {
+                    ev[k] = A.ed[first + j];
+                    nsum += ev[k].y;
+                }
+            }
+            const u32 ntot = wave_sum_u32(nsum);
+            const float sq = sqrtf((float)(1u + ntot));
+            float best = -INFINITY;
+            int bj = -1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = lane + 64 * k;
+                if (k < rounds && j < M) {
+                    const float prior = u2f(ev[k].x);
+                    const u32 n = ev[k].y;
+                    const float W = u2f(ev[k].z);
+                    const float q = n ? W / (float)n : 0.0f;
+                    const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
+                    const float score = u + q;
+                    if (score > best || (score == best && j > bj)) {
+                        best = score;
+                        bj = j;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ob = __shfl_xor(best, off, 64);
+                const int oj = __shfl_xor(bj, off, 64);
+                if (ob > best || (ob == best && oj > bj)) {
+                    best = ob;
+                    bj = oj;
+                }
+            }
+            if (bj < 0)
+                bj = 0;
+            const u32 eidx = first + (u32)bj;
+            if (lane == 0)
+                path[depth] = (int)eidx;
+            depth++;
+            const int kk = bj >> 6;
+            const u32 mine = kk == 0 ? ev[0].w : (kk == 1 ? ev[1].w : (kk == 2 ? ev[2].w : ev[3].w));
+            const u32 child = (u32)__shfl((int)mine, bj & 63, 64);
+            if (child != NONE) {
+                node = child;
+                continue;
+            }
+            // expand (:429-439)
+            const u32 mv = A.em[eidx];
+            const ulonglong2 pw = A.nb[node];
+            const Board cb = make_move(unpack_board(pw.x, pw.y), (int)(mv & 0xFF), (int)(mv >> 8));
+            int res2;
+            const int M2 = wave_movegen(cb, P.blockers, s_moves, &res2);
+            __syncthreads();
+            if (s.n_nodes >= P.node_cap || (res2 == 0 && s.n_edges + M2 > P.edge_cap)) {
+                over = 1;
+                kind = AZH_LEAF_NONE;
+                leaf_node = 0;
+                depth = 0;
+                break;
+            }
+            const u32 cid = (u32)s.n_nodes;
+            s.n_nodes += 1;
+            if (res2 != 0) {
+                float tv = res2 == 1 ? 1.0f : -1.0f;
+                if (cb.turn == 1)
+                    tv = -tv;
+                if (lane == 0)
+                    A.ni[cid] = make_uint4(0u, (u32)res2 << 16, 0u, f2u(tv));
+                kind = AZH_LEAF_TERMINAL;
+            } else {
+                const u32 nf = (u32)s.n_edges;
+                for (int j = lane; j < M2; j += WAVE) {
+                    A.ed[nf + j] = make_uint4(0u, 0u, 0u, NONE);
+                    A.em[nf + j] = s_moves[j];
+                }
+                s.n_edges += M2;
+                if (lane == 0)
+                    A.ni[cid] = make_uint4(nf, (u32)M2, 0u, 0u);
+                kind = AZH_LEAF_EVAL;
+                st_evals = 1;
+                st_newmoves = (u64)M2;
+            }
+            if (lane == 0) {
+                A.nb[cid] = make_ulonglong2(pack_word0(cb), cb.o);
+                reinterpret_cast<u32 *>(&A.ed[eidx])[3] = cid;
+            }
+            leaf_node = (int)cid;
+            leaf_mover = cb.turn ? cb.o : cb.x;
+            leaf_opp = cb.turn ? cb.x : cb.o;
+            break;
+        }
+    }
+
+    if (lane == 0) {
+        s.leaf_kind = kind;
+        s.leaf_node = leaf_node;
+        s.path_len = depth;
+        P.gs[g] = s;
+        P.need_eval[g] = (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) ? 1 : 0;
+        P.leaf_board[g] = make_ulonglong2(leaf_mover, leaf_opp);
+        if (over)
+            P.force[g] = 1;
+        add_stat(P, g, AZH_STAT_STEPS, st_steps);
+        add_stat(P, g, AZH_STAT_NN_EVALS, st_evals);
+        add_stat(P, g, AZH_STAT_LEVELS, st_levels);
+        add_stat(P, g, AZH_STAT_CHILDREN, st_children);
+        add_stat(P, g, AZH_STAT_NEW_MOVES, st_newmoves);
+        add_stat(P, g, AZH_STAT_EDGE_OVERFLOW, (u64)over);
+    }
+}
+
+// Dense, game-ordered list of the games whose leaf needs the evaluator.
+__global__ __launch_bounds__(1024) void k_compact(const int *need, int G, int *list, int *count)
+{
+    __shared__ int s_sum[1024];
+    const int t = threadIdx.x;
+    const int c = (G + 1023) / 1024;
+    const int lo = t * c, hi = min(G, lo + c);
+    int cnt = 0;
+    for (int i = lo; i < hi; i++)
+        cnt += need[i] != 0;
+    s_sum[t] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? s_sum[t - off] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int base = s_sum[t] - cnt;
+    for (int i = lo; i < hi; i++)
+        if (need[i])
+            list[base++] = i;
+    if (t == 1023)
+        *count = s_sum[1023];
+}
+
+// ------------------------------------------------------------------ priors + backup
+
+__global__ __launch_bounds__(WAVE) void k_backup(EngineParams P)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    azh_game_state s = P.gs[g];
+    const int kind = s.leaf_kind;
+    if (kind == AZH_LEAF_NONE)
+        return;
+    Arena A = arena_of(P, s.arena, g);
+
+    if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) {
+        // Evaluations::populate (:204-271): softmax over the legal moves' logits —
+        // identical to the reference's 833-way softmax renormalised over the legal
+        // moves — then the Dirichlet mix at the root.
+        const uint4 info = A.ni[s.leaf_node];
+        const u32 first = info.x;
+        const int M = (int)(info.y & 0xFFFFu);
+        const int rounds = (M + 63) >> 6;
+        const float *row = P.logits + (size_t)g * AZH_POLICY_SIZE;
+        float l[4], ex[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = lane + 64 * k;
+            l[k] = -INFINITY;
+            if (k < rounds && j < M) {
+                l[k] = row[policy_index(A.em[first + j])];
+                if (l[k] > mx)
+                    mx = l[k];
+            }
+        }
+        mx = wave_max_f32(mx);
+        float part = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = lane + 64 * k;
+            ex[k] = 0.0f;
+            if (k < rounds && j < M) {
+                ex[k] = det_expf(l[k] - mx);
+                part = part + ex[k];
+            }
+        }
+        const float S = wave_sum_f32(part);
+        float pr[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            pr[k] = S > 0.0f ? ex[k] / S : ex[k];
+        if (kind == AZH_LEAF_ROOT && P.noise_w > 0.0f) {
+            float gm[4];
+            float gpart = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = lane + 64 * k;
+                gm[k] = 0.0f;
+                if (k < rounds && j < M) {
+                    gm[k] = det_gamma(P.alpha, P.k0, P.k1, s.uid, (u32)s.ply, (u32)j);
+                    gpart = gpart + gm[k];
+                }
+            }
+            const float T = wave_sum_f32(gpart);
+            const float w = P.noise_w, omw = 1.0f - w;
+            if (T > 0.0f) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float d = gm[k] / T;
+                    const float t1 = w * d;
+                    const float t2 = omw * pr[k];
+                    pr[k] = t1 + t2;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = lane + 64 * k;
+            if (k < rounds && j < M)
+                reinterpret_cast<u32 *>(&A.ed[first + j])[0] = f2u(pr[k]);
+        }
+    }
+
+    if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_TERMINAL) {
+        // step() part 4 (:449-459): flip the score at every edge on the way up.
+        const float v = kind == AZH_LEAF_EVAL ? P.values[g] : u2f(A.ni[s.leaf_node].w);
+        const float sc0 = (v + 1.0f) * 0.5f;
+        const float fa = 1.0f - sc0, fb = 1.0f - fa, fc = 1.0f - fb;
+        const int *path = P.path + (size_t)g * P.path_cap;
+        for (int i = lane; i < s.path_len; i += WAVE) {
+            const int flips = s.path_len - i;
+            const float val = flips == 1 ? fa : ((flips & 1) ? fc : fb);
+            u32 *e = reinterpret_cast<u32 *>(&A.ed[path[i]]);
+            e[2] = f2u(u2f(e[2]) + val);
+            e[1] += 1u;
+        }
+        if (s.path_len > 0)
+            s.root_visits += 1;
+    }
+    if (lane == 0) {
+        if (kind == AZH_LEAF_ROOT)
+            s.phase = 1;
+        s.leaf_kind = AZH_LEAF_NONE;
+        P.gs[g] = s;
+    }
+}
+
+// ------------------------------------------------------------------ ply advance
+
+__global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
+{
+    __shared__ u16 s_moves[MAX_MOVES];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    azh_game_state s = P.gs[g];
+    // while (root.all_edge_visits < global_visits) step();  (:522-525)
+    if (!(s.phase == 1 && (s.root_visits >= P.visits || P.force[g] != 0)))
+        return;
+    Arena A = arena_of(P, s.arena, g);
+    Arena B = arena_of(P, 1 - s.arena, g);
+    const uint4 rinfo = A.ni[0];
+    const u32 first = rinfo.x;
+    const int M = (int)(rinfo.y & 0xFFFFu);
+
+    // sample_proportionally_to_visits (:495-506) on integer visit counts
+    const Philox4 rr = philox(P.k0, P.k1, s.uid, (u32)s.ply, STREAM_SAMPLE, 0u);
+    const u32 N = (u32)s.root_visits;
+    const u32 r = (u32)(((u64)rr.v[0] * (u64)N) >> 32);
+    uint4 ev[4];
+    u32 mvs[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = lane + 64 * k;
+        ev[k] = make_uint4(0u, 0u, 0u, NONE);
+        mvs[k] = 0;
+        if (j < M) {
+            ev[k] = A.ed[first + j];
+            mvs[k] = A.em[first + j];
+        }
+    }
+    int chosen = -1;
+    u32 run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = lane + 64 * k;
+        const int incl = wave_incl_scan((int)ev[k].y);
+        const u32 cum = run + (u32)incl;
+        const u64 mask = __ballot(j < M && cum > r);
+        if (chosen < 0 && mask)
+            chosen = 64 * k + (__ffsll((long long)mask) - 1);
+        run += (u32)__shfl(incl, 63, 64);
+    }
+    if (chosen < 0)
+        chosen = 0;
+
+    // record the ply (:565-572): board, move, visit distribution over expanded edges
+    u32 *rec = P.rec + ((size_t)g * P.max_plies + s.ply) * REC_STRIDE_WORDS;
+    const u64 lt = (1ULL << lane) - 1ULL;
+    int nd = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = lane + 64 * k;
+        const bool has = j < M && ev[k].w != NONE;
+        const u64 mask = __ballot(has);
+        if (has)
+            rec[REC_HDR_WORDS + nd + __popcll(mask & lt)] = mvs[k] | ((ev[k].y & 0xFFFFu) << 16);
+        nd += __popcll(mask);
+    }
+    const int ck = chosen >> 6, cl = chosen & 63;
+    const u32 my_mv = ck == 0 ? mvs[0] : (ck == 1 ? mvs[1] : (ck == 2 ? mvs[2] : mvs[3]));
+    const u32 my_ch = ck == 0 ? ev[0].w : (ck == 1 ? ev[1].w : (ck == 2 ? ev[2].w : ev[3].w));
+    const u32 mv = (u32)__shfl((int)my_mv, cl, 64);
+    const u32 c = (u32)__shfl((int)my_ch, cl, 64);
+    const ulonglong2 rootw = A.nb[0];
+    if (lane == 0) {
+        const u64 bx = rootw.x & ~TURN_BIT;
+        rec[0] = (u32)bx;
+        rec[1] = (u32)(bx >> 32);
+        rec[2] = (u32)rootw.y;
+        rec[3] = (u32)(rootw.y >> 32);
+        rec[4] = (mv & 0xFFFFu) | ((u32)nd << 16);
+        rec[5] = 0;
+        rec[6] = 0;
+        rec[7] = 0;
+    }
+
+    // MCTS::play (:475-492): keep the chosen child's subtree, compacted breadth-first
+    // into the other arena (children keep their edge order).
+    int result;
+    u64 st_nodes = 0, st_edges = 0;
+    if (c == NONE) {
+        // miss: fresh tree from the position after the move (:479-483)
+        const Board nbrd = make_move(unpack_board(rootw.x, rootw.y), (int)(mv & 0xFF), (int)(mv >> 8));
+        const int Mn = wave_movegen(nbrd, P.blockers, s_moves, &result);
+        __syncthreads();
+        const int Mw = result != 0 ? 0 : Mn;
+        for (int j = lane; j < Mw; j += WAVE) {
+            B.ed[j] = make_uint4(0u, 0u, 0u, NONE);
+            B.em[j] = s_moves[j];
+        }
+        if (lane == 0) {
+            float tv = result == 1 ? 1.0f : -1.0f;
+            if (nbrd.turn == 1)
+                tv = -tv;
+            B.nb[0] = make_ulonglong2(pack_word0(nbrd), nbrd.o);
+            B.ni[0] = result != 0 ? make_uint4(0u, (u32)result << 16, 0u, f2u(tv)) : make_uint4(0u, (u32)Mw, 0u, 0u);
+        }
+        s.n_nodes = 1;
+        s.n_edges = Mw;
+        s.root_visits = 0;
+    } else {
+        const uint4 cinfo = A.ni[c];
+        result = (int)(cinfo.y >> 16);
+        if (lane == 0) {
+            B.nb[0] = A.nb[c];
+            B.ni[0] = cinfo;
+        }
+        __syncthreads();
+        u32 t = 1, eb = 0, rv = 0;
+        for (u32 q = 0; q < t; q++) {
+            const uint4 qi = B.ni[q];
+            const u32 of = qi.x, Mq = qi.y & 0xFFFFu, nf = eb;
+            eb += Mq;
+            for (u32 j0 = 0; j0 < Mq; j0 += WAVE) {
+                const u32 j = j0 + (u32)lane;
+                const bool valid = j < Mq;
+                uint4 e = make_uint4(0u, 0u, 0u, NONE);
+                u16 m = 0;
+                if (valid) {
+                    e = A.ed[of + j];
+                    m = A.em[of + j];
+                }
+                const bool has = valid && e.w != NONE;
+                const u64 mask = __ballot(has);
+                if (has) {
+                    const u32 nc = t + (u32)__popcll(mask & lt);
+                    B.nb[nc] = A.nb[e.w];
+                    B.ni[nc] = A.ni[e.w];
+                    e.w = nc;
+                }
+                if (valid) {
+                    B.ed[nf + j] = e;
+                    B.em[nf + j] = m;
+                    if (q == 0)
+                        rv += e.y;
+                }
+                t += (u32)__popcll(mask);
+            }
+            if (lane == 0)
+                reinterpret_cast<u32 *>(&B.ni[q])[0] = Mq ? nf : 0u;
+            __syncthreads();
+        }
+        s.n_nodes = (int)t;
+        s.n_edges = (int)eb;
+        s.root_visits = (int)wave_sum_u32(rv);
+        st_nodes = t;
+        st_edges = eb;
+    }
+    s.arena = 1 - s.arena;
+    s.ply += 1;
+    __syncthreads();
+
+    u64 st_games = 0, st_dropped = 0, st_ring = 0;
+    if (result != 0) {
+        // finished: emit the packed record (generate_game :577-578, Worker :637-642)
+        const u32 *recg = P.rec + (size_t)g * P.max_plies * REC_STRIDE_WORDS;
+        int words = 0;
+        for (int p = lane; p < s.ply; p += WAVE)
+            words += 6 + (int)(recg[(size_t)p * REC_STRIDE_WORDS + 4] >> 16);
+        words = wave_sum_int(words) + 8;
+        u64 off = 0;
+        if (lane == 0)
+            off = atomicAdd((unsigned long long *)P.ring_head, (unsigned long long)words);
+        off = ((u64)(u32)__shfl((int)(off >> 32), 0, 64) << 32) | (u64)(u32)__shfl((int)off, 0, 64);
+        if (off + (u64)words <= P.ring_cap_words) {
+            u32 *out = P.ring + off;
+            if (lane == 0) {
+                out[0] = RING_MAGIC;
+                out[1] = (u32)g;
+                out[2] = s.uid;
+                out[3] = (u32)s.ply;
+                out[4] = (u32)result;
+                out[5] = (u32)words;
+                out[6] = 0;
+                out[7] = 0;
+            }
+            u32 pos = 8;
+            for (int p = 0; p < s.ply; p++) {
+                const u32 *rp = recg + (size_t)p * REC_STRIDE_WORDS;
+                const u32 ndp = rp[4] >> 16;
+                if (lane < 6)
+                    out[pos + lane] = rp[lane];
+                for (u32 j = lane; j < ndp; j += WAVE)
+                    out[pos + 6 + j] = rp[REC_HDR_WORDS + j];
+                pos += 6 + ndp;
+            }
+            st_games = 1;
+        } else {
+            st_ring = 1;
+        }
+        init_game(P, g, s.uid + (u32)P.G, s, s_moves);
+    } else if (s.ply >= P.max_plies) {
+        st_dropped = 1;  // null-result games are skipped (:628-631)
+        init_game(P, g, s.uid + (u32)P.G, s, s_moves);
+    } else {
+        s.phase = 0;
+    }
+    if (lane == 0) {
+        P.force[g] = 0;
+        P.gs[g] = s;
+        add_stat(P, g, AZH_STAT_PLIES, 1);
+        add_stat(P, g, AZH_STAT_GAMES, st_games);
+        add_stat(P, g, AZH_STAT_DROPPED, st_dropped);
+        add_stat(P, g, AZH_STAT_RING_OVERFLOW, st_ring);
+        add_stat(P, g, AZH_STAT_REROOT_NODES, st_nodes);
+        add_stat(P, g, AZH_STAT_REROOT_EDGES, st_edges);
+    }
+}
+
+// Reference feature rows for the dense leaf list (cpp/self_play_client.cpp:174-202).
+__global__ void k_features(const ulonglong2 *boards, const int *list, int n, u64 blockers, float *out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * 49)
+        return;
+    const int row = idx / 49, c = idx % 49;
+    const int x = c / 7, y = c % 7, sq = x + 7 * (6 - y);
+    const ulonglong2 b = boards[list ? list[row] : row];
+    float4 f;
+    f.x = 1.0f;
+    f.y = (float)((b.x >> sq) & 1ULL);
+    f.z = (float)((b.y >> sq) & 1ULL);
+    f.w = (float)((blockers >> sq) & 1ULL);
+    reinterpret_cast<float4 *>(out)[idx] = f;
+}
+
+__global__ void k_reduce_stats(const u64 *stats, int G, u64 *out)
+{
+    const int k = blockIdx.x;
+    u64 acc = 0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+        acc += stats[(size_t)g * NSTAT + k];
+    __shared__ u64 s_acc[256];
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            s_acc[threadIdx.x] += s_acc[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[k] = s_acc[0];
+}
+
+}  // namespace azh
+
+using namespace azh;
+
+// ------------------------------------------------------------------ host
+
+std::string azh_format_game_json(const uint32_t *rec, size_t words);  // json.cpp
+
+struct azh_engine {
+    azh_config cfg;
+    EngineParams P;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    float *d_feat = nullptr;
+    u64 *d_stat_out = nullptr;
+    // finished games formatted but not yet handed out
+    std::vector<std::string> pending;
+    size_t pending_pos = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> events;  // 4 per recorded iteration
+    size_t ev_used = 0;
+    std::vector<int> ev_evals;
+    int *h_count = nullptr;  // pinned
+    bool selected = false;
+};
+
+static const size_t MAX_TIMED_ITERS = 4096;
+
+template <typename T> static int dev_alloc(azh_engine *e, T **p, size_t count)
+{
+    void *q = nullptr;
+    AZH_HIP(hipMalloc(&q, count * sizeof(T)));
+    AZH_HIP(hipMemset(q, 0, count * sizeof(T)));
+    e->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
+{
+    if (!cfg || !out)
+        return azh_fail(-1, "azh_engine_create: null argument");
+    if (cfg->games <= 0 || cfg->visits <= 0 || cfg->visits > 60000 || cfg->max_plies <= 0 ||
+        cfg->edges_per_node < 8)
+        return azh_fail(-2, "azh_engine_create: bad config (games %d visits %d max_plies %d edges_per_node %d)",
+                        cfg->games, cfg->visits, cfg->max_plies, cfg->edges_per_node);
+    if (azh_require_device())
+        return -3;
+    azh_engine *e = new azh_engine();
+    e->cfg = *cfg;
+    EngineParams &P = e->P;
+    memset(&P, 0, sizeof(P));
+    P.G = cfg->games;
+    P.visits = cfg->visits;
+    P.node_cap = cfg->visits + 8;
+    P.edge_cap = P.node_cap * cfg->edges_per_node;
+    P.path_cap = P.node_cap;
+    P.max_plies = cfg->max_plies;
+    P.c_puct = cfg->c_puct;
+    P.alpha = cfg->dirichlet_alpha;
+    P.noise_w = cfg->dirichlet_weight;
+    P.k0 = (u32)cfg->seed;
+    P.k1 = (u32)(cfg->seed >> 32);
+    P.start_x = cfg->start_x;
+    P.start_o = cfg->start_o;
+    P.blockers = cfg->blockers;
+    P.start_turn = cfg->start_turn;
+    const size_t G = (size_t)P.G;
+    // ring of finished-game records (64 KiB per slot between two drains)
+    P.ring_cap_words = std::max<size_t>((size_t)1 << 22, G * 16384);
+    int rc = 0;
+    rc |= dev_alloc(e, &P.gs, G);
+    rc |= dev_alloc(e, &P.force, G);
+    rc |= dev_alloc(e, &P.path, G * P.path_cap);
+    rc |= dev_alloc(e, &P.node_board, 2 * G * P.node_cap);
+    rc |= dev_alloc(e, &P.node_info, 2 * G * P.node_cap);
+    rc |= dev_alloc(e, &P.edge, 2 * G * P.edge_cap);
+    rc |= dev_alloc(e, &P.edge_move, 2 * G * P.edge_cap);
+    rc |= dev_alloc(e, &P.leaf_board, G);
+    rc |= dev_alloc(e, &P.need_eval, G);
+    rc |= dev_alloc(e, &P.leaf_list, G);
+    rc |= dev_alloc(e, &P.leaf_count, 1);
+    rc |= dev_alloc(e, &P.logits, G * AZH_POLICY_SIZE);
+    rc |= dev_alloc(e, &P.values, G);
+    rc |= dev_alloc(e, &P.rec, G * P.max_plies * REC_STRIDE_WORDS);
+    rc |= dev_alloc(e, &P.ring, P.ring_cap_words);
+    rc |= dev_alloc(e, &P.ring_head, 1);
+    rc |= dev_alloc(e, &P.stats, G * NSTAT);
+    rc |= dev_alloc(e, &e->d_stat_out, NSTAT);
+    if (rc) {
+        azh_engine_destroy(e);
+        return rc;
+    }
+    if (hipStreamCreate(&e->stream) != hipSuccess || hipHostMalloc((void **)&e->h_count, sizeof(int)) != hipSuccess) {
+        azh_engine_destroy(e);
+        return azh_fail(-4, "azh_engine_create: stream / pinned allocation failed");
+    }
+    hipLaunchKernelGGL(k_init, dim3(P.G), dim3(WAVE), 0, e->stream, P);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) {
+        azh_engine_destroy(e);
+        return azh_fail(-5, "azh_engine_create: init kernel failed");
+    }
+    *out = e;
+    return 0;
+}
+
+extern "C" void azh_engine_destroy(azh_engine *e)
+{
+    if (!e)
+        return;
+    if (e->stream)
+        (void)hipStreamSynchronize(e->stream);
+    for (auto ev : e->events)
+        (void)hipEventDestroy(ev);
+    for (void *p : e->allocs)
+        (void)hipFree(p);
+    if (e->d_feat)
+        (void)hipFree(e->d_feat);
+    if (e->h_count)
+        (void)hipHostFree(e->h_count);
+    if (e->stream)
+        (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int azh_engine_node_cap(const azh_engine *e) { return e ? e->P.node_cap : -1; }
+extern "C" int azh_engine_edge_cap(const azh_engine *e) { return e ? e->P.edge_cap : -1; }
+
+static int enqueue_select(azh_engine *e)
+{
+    hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->stream, e->P.need_eval, e->P.G, e->P.leaf_list,
+                       e->P.leaf_count);
+    AZH_HIP(hipGetLastError());
+    return 0;
+}
+
+static int enqueue_backup(azh_engine *e)
+{
+    hipLaunchKernelGGL(k_backup, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
+    hipLaunchKernelGGL(k_advance, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
+    AZH_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int azh_engine_select(azh_engine *e, int32_t *n_leaves_out)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_select: null engine");
+    if (enqueue_select(e))
+        return -1;
+    AZH_HIP(hipMemcpyAsync(e->h_count, e->P.leaf_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    e->selected = true;
+    if (n_leaves_out)
+        *n_leaves_out = *e->h_count;
+    return 0;
+}
+
+extern "C" int azh_engine_leaves(azh_engine *e, int32_t *need_eval, uint64_t *leaf_boards)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_leaves: null engine");
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    if (need_eval)
+        AZH_HIP(hipMemcpy(need_eval, e->P.need_eval, (size_t)e->P.G * 4, hipMemcpyDeviceToHost));
+    if (leaf_boards)
+        AZH_HIP(hipMemcpy(leaf_boards, e->P.leaf_board, (size_t)e->P.G * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Dense feature rows of the current leaf batch, in leaf-list (game) order.
+extern "C" int azh_engine_leaf_features(azh_engine *e, float *out, int32_t *games_out)
+{
+    if (!e || !out)
+        return azh_fail(-1, "azh_engine_leaf_features: null argument");
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    int n = 0;
+    AZH_HIP(hipMemcpy(&n, e->P.leaf_count, 4, hipMemcpyDeviceToHost));
+    if (n <= 0)
+        return 0;
+    if (!e->d_feat)
+        AZH_HIP(hipMalloc((void **)&e->d_feat, (size_t)e->P.G * AZH_FEATURE_SIZE * 4));
+    hipLaunchKernelGGL(k_features, dim3((n * 49 + 255) / 256), dim3(256), 0, e->stream,
+                       (const ulonglong2 *)e->P.leaf_board, (const int *)e->P.leaf_list, n, e->P.blockers, e->d_feat);
+    AZH_HIP(hipGetLastError());
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    AZH_HIP(hipMemcpy(out, e->d_feat, (size_t)n * AZH_FEATURE_SIZE * 4, hipMemcpyDeviceToHost));
+    if (games_out)
+        AZH_HIP(hipMemcpy(games_out, e->P.leaf_list, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int azh_engine_eval(azh_engine *e, azh_net *net, int dtype)
+{
+    if (!e || !net)
+        return azh_fail(-1, "azh_engine_eval: null argument");
+    return azh_net_launch(net, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list, e->P.leaf_count,
+                          e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
+}
+
+extern "C" int azh_engine_set_evals(azh_engine *e, const float *logits, const float *values)
+{
+    if (!e || !logits || !values)
+        return azh_fail(-1, "azh_engine_set_evals: null argument");
+    AZH_HIP(hipMemcpyAsync(e->P.logits, logits, (size_t)e->P.G * AZH_POLICY_SIZE * 4, hipMemcpyHostToDevice, e->stream));
+    AZH_HIP(hipMemcpyAsync(e->P.values, values, (size_t)e->P.G * 4, hipMemcpyHostToDevice, e->stream));
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int azh_engine_backup(azh_engine *e)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_backup: null engine");
+    if (enqueue_backup(e))
+        return -1;
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    e->selected = false;
+    return 0;
+}
+
+extern "C" int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations)
+{
+    if (!e || !net || iterations < 0)
+        return azh_fail(-1, "azh_engine_run: bad argument");
+    for (int it = 0; it < iterations; it++) {
+        const bool rec = e->timing && e->ev_used + 4 <= e->events.size();
+        hipEvent_t *ev = rec ? &e->events[e->ev_used] : nullptr;
+        if (rec) AZH_HIP(hipEventRecord(ev[0], e->stream));
+        if (enqueue_select(e)) return -1;
+        if (rec) AZH_HIP(hipEventRecord(ev[1], e->stream));
+        int rc = azh_engine_eval(e, net, dtype);
+        if (rc) return rc;
+        if (rec) AZH_HIP(hipEventRecord(ev[2], e->stream));
+        if (enqueue_backup(e)) return -1;
+        if (rec) {
+            AZH_HIP(hipEventRecord(ev[3], e->stream));
+            e->ev_used += 4;
+        }
+    }
+    return 0;
+}
+
+extern "C" int azh_engine_sync(azh_engine *e)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_sync: null engine");
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out)
+{
+    if (!e || !out || game < 0 || game >= e->P.G)
+        return azh_fail(-1, "azh_engine_game_state: bad argument");
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    AZH_HIP(hipMemcpy(out, e->P.gs + game, sizeof(azh_game_state), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int azh_engine_tree(azh_engine *e, int game, uint64_t *boards, uint32_t *info, uint32_t *edges,
+                               uint16_t *moves)
+{
+    if (!e || game < 0 || game >= e->P.G)
+        return azh_fail(-1, "azh_engine_tree: bad argument");
+    azh_game_state s;
+    if (azh_engine_game_state(e, game, &s))
+        return -1;
+    const size_t slot = (size_t)s.arena * e->P.G + game;
+    if (boards) AZH_HIP(hipMemcpy(boards, e->P.node_board + slot * e->P.node_cap, (size_t)s.n_nodes * 16, hipMemcpyDeviceToHost));
+    if (info) AZH_HIP(hipMemcpy(info, e->P.node_info + slot * e->P.node_cap, (size_t)s.n_nodes * 16, hipMemcpyDeviceToHost));
+    if (edges) AZH_HIP(hipMemcpy(edges, e->P.edge + slot * e->P.edge_cap, (size_t)s.n_edges * 16, hipMemcpyDeviceToHost));
+    if (moves) AZH_HIP(hipMemcpy(moves, e->P.edge_move + slot * e->P.edge_cap, (size_t)s.n_edges * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int azh_engine_stats(azh_engine *e, uint64_t *out)
+{
+    if (!e || !out)
+        return azh_fail(-1, "azh_engine_stats: bad argument");
+    hipLaunchKernelGGL(k_reduce_stats, dim3(NSTAT), dim3(256), 0, e->stream, (const u64 *)e->P.stats, e->P.G, e->d_stat_out);
+    AZH_HIP(hipGetLastError());
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    AZH_HIP(hipMemcpy(out, e->d_stat_out, NSTAT * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int azh_engine_timing_reset(azh_engine *e, int enable)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_timing_reset: null engine");
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    e->timing = enable != 0;
+    e->ev_used = 0;
+    if (e->timing && e->events.empty()) {
+        e->events.resize(4 * MAX_TIMED_ITERS);
+        for (auto &ev : e->events)
+            AZH_HIP(hipEventCreate(&ev));
+    }
+    return 0;
+}
+
+extern "C" int azh_engine_timing(azh_engine *e, azh_timing *out)
+{
+    if (!e || !out)
+        return azh_fail(-1, "azh_engine_timing: bad argument");
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    memset(out, 0, sizeof(*out));
+    for (size_t i = 0; i + 4 <= e->ev_used; i += 4) {
+        float a = 0, b = 0, c = 0;
+        AZH_HIP(hipEventElapsedTime(&a, e->events[i], e->events[i + 1]));
+        AZH_HIP(hipEventElapsedTime(&b, e->events[i + 1], e->events[i + 2]));
+        AZH_HIP(hipEventElapsedTime(&c, e->events[i + 2], e->events[i + 3]));
+        out->select_ms += a;
+        out->net_ms += b;
+        out->backup_ms += c;
+        out->iterations += 1;
+    }
+    return 0;
+}
+
+extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, int32_t *n_games)
+{
+    if (!e || !buf || !used || !n_games)
+        return azh_fail(-1, "azh_engine_drain_json: null argument");
+    *used = 0;
+    *n_games = 0;
+    if (e->pending_pos >= e->pending.size()) {
+        e->pending.clear();
+        e->pending_pos = 0;
+        AZH_HIP(hipStreamSynchronize(e->stream));
+        u64 head = 0;
+        AZH_HIP(hipMemcpy(&head, e->P.ring_head, 8, hipMemcpyDeviceToHost));
+        if (head > e->P.ring_cap_words)
+            head = e->P.ring_cap_words;
+        if (head > 0) {
+            std::vector<uint32_t> host((size_t)head);
+            AZH_HIP(hipMemcpy(host.data(), e->P.ring, (size_t)head * 4, hipMemcpyDeviceToHost));
+            AZH_HIP(hipMemset(e->P.ring, 0, (size_t)head * 4));
+            AZH_HIP(hipMemset(e->P.ring_head, 0, 8));
+            std::vector<std::pair<uint32_t, size_t>> order;  // (uid, offset)
+            size_t pos = 0;
+            while (pos + 8 <= host.size() && host[pos] == RING_MAGIC) {
+                const size_t words = host[pos + 5];
+                if (words < 8 || pos + words > host.size())
+                    break;
+                order.emplace_back(host[pos + 2], pos);
+                pos += words;
+            }
+            std::sort(order.begin(), order.end());
+            for (auto &o : order)
+                e->pending.push_back(azh_format_game_json(host.data() + o.second, host[o.second + 5]));
+        }
+    }
+    while (e->pending_pos < e->pending.size()) {
+        const std::string &line = e->pending[e->pending_pos];
+        if (*used + (int64_t)line.size() + 1 > cap)
+            break;
+        memcpy(buf + *used, line.data(), line.size());
+        buf[*used + line.size()] = '\n';
+        *used += (int64_t)line.size() + 1;
+        *n_games += 1;
+        e->pending_pos++;
+    }
+    if (*n_games == 0 && e->pending_pos < e->pending.size())
+        return azh_fail(-6, "azh_engine_drain_json: buffer of %lld bytes cannot hold one game line (%zu bytes)",
+                        (long long)cap, e->pending[e->pending_pos].size() + 1);
+    return 0;
+}

@@ -1,0 +1,572 @@
+// Fused policy/value tower for gfx950 (MI355X): the whole residual conv net of
+// model.py:38-79 in ONE kernel, activations resident in LDS from the first
+// convolution to the heads, every contraction on MFMA.
+//
+// Math (reference model.py:116-142, TF semantics stated in SURVEY.md §8 a7):
+//   h0 = relu(bn(conv3x3(features)))                       model.py:56-57
+//   per block: t = relu(bn(conv3x3(h))); h = relu(bn(conv3x3(t)) + h)   :132-142
+//   policy = conv1x1(h)  (17 raw logits per cell)          model.py:66-69
+//   value  = tanh(reshape(conv1x1(h), 49) . fc_w + fc_b)   model.py:71-79
+// conv = NHWC/HWIO cross-correlation with SAME zero padding; bn is the loaded
+// inference form (x - mean) / sqrt(var + eps), gamma = 1, beta = 0.
+//
+// Mapping.  Every convolution is the implicit GEMM
+//     out^T[oc][cell] = sum_k W^T[oc][k] * im2col^T[k][cell],   k = (tap, channel)
+// with the WEIGHTS as the MFMA A operand (rows = 32 output channels per wave) and
+// the ACTIVATIONS as the B operand (columns = 32 board cells).  The 32x32 f32
+// accumulator then holds, per lane, 16 output channels of ONE cell in groups of
+// four consecutive channels, so the epilogue (bn, skip, relu, convert) writes
+// 8-byte runs straight back into the [cell][channel] LDS image that the next
+// layer reads as its B operand: no transpose, no global round trip.
+//
+// A workgroup = 4 waves = BOARDS boards (6 for 16-bit types, 3 for f32); wave w
+// owns output channels [32w, 32w+32).  LDS holds two activation images
+// [cells + 1 zero row][128 ch]; taps that fall off the board read the zero row.
+// Rows are 256 B (16-bit) / 512 B (f32) — a multiple of the LDS bank row — so
+// 16-byte chunks are XOR-swizzled with the cell index to keep the 32 cells of a
+// B-fragment read on distinct banks.
+// Weights are pre-packed on the host in exact A-fragment order (1 KiB per
+// wave-instruction), streamed from L2 with a two-deep register prefetch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "azh_host.h"
+
+namespace azh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int F = 128;        // filters (model.py:16)
+constexpr int OCT = F / 32;   // 32-channel output tiles = waves per workgroup
+constexpr int NTHREADS = 64 * OCT;
+
+template <int DT> struct Traits;
+
+template <> struct Traits<AZH_DTYPE_BF16> {
+    typedef __bf16 elem;
+    typedef bf16x8 afrag;     // 8 consecutive k of one output channel
+    typedef bf16x4 quad;
+    static constexpr int KSTEP = 16;   // k per MFMA
+    static constexpr int BOARDS = 6;
+    static constexpr int ESIZE = 2;
+    __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Traits<AZH_DTYPE_F16> {
+    typedef _Float16 elem;
+    typedef f16x8 afrag;
+    typedef f16x4 quad;
+    static constexpr int KSTEP = 16;
+    static constexpr int BOARDS = 6;
+    static constexpr int ESIZE = 2;
+    __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Traits<AZH_DTYPE_F32> {
+    typedef float elem;
+    typedef float afrag;      // one k of one output channel
+    typedef f32x4 quad;
+    static constexpr int KSTEP = 2;
+    static constexpr int BOARDS = 3;
+    static constexpr int ESIZE = 4;
+    __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+
+template <int DT> struct Geo {
+    typedef Traits<DT> Tr;
+    static constexpr int BOARDS = Tr::BOARDS;
+    static constexpr int NC = 49 * BOARDS;             // real cells per workgroup
+    static constexpr int NT = (NC + 31) / 32;          // 32-cell MFMA column tiles
+    static constexpr int ROWB = F * Tr::ESIZE;         // bytes per cell row
+    static constexpr int IMG = (NC + 1) * ROWB;        // one activation image (+ zero row)
+    static constexpr int STAGE_OFF = 2 * IMG;          // f32 value-cell scratch
+    static constexpr int LDS_BYTES = 2 * IMG + NC * 4;
+    static constexpr int KSTEPS_FULL = F / Tr::KSTEP;  // k-steps per tap, 128-channel input
+    static constexpr int KSTEPS_IN = (Tr::KSTEP >= 4) ? 1 : 4 / Tr::KSTEP;  // 4 input planes
+};
+
+// Byte offset of the 16-byte (16-bit types) or 4-byte (f32) unit `u` of row `row`.
+template <int DT> __device__ inline int unit_off(int row, int u)
+{
+    if constexpr (DT == AZH_DTYPE_F32)
+        return row * Geo<DT>::ROWB + ((u ^ (row & 31)) << 2);
+    else
+        return row * Geo<DT>::ROWB + ((u ^ (row & 15)) << 4);
+}
+
+struct TowerArgs {
+    const void *conv_w;      // packed A fragments, all tower layers back to back
+    const void *head_w;      // packed A fragments of the fused policy+value 1x1 conv
+    const float *scale;      // [2B+1][128]  1/sqrt(var+eps)
+    const float *shift;      // [2B+1][128]  -mean*scale
+    const float *fc_w;       // [49]
+    float fc_b;
+    int blocks;
+    const unsigned long long *boards;  // [..][2] (mover, opponent), indexed by game
+    const int *list;         // dense list of games to evaluate (or nullptr = identity)
+    const int *count;        // device count (or nullptr -> n)
+    int n;
+    unsigned long long blockers;
+    float *logits;           // [..][833], indexed by game
+    float *values;           // [..], indexed by game
+};
+
+template <int DT>
+__device__ inline void conv_layer(const unsigned char *in, unsigned char *out, const unsigned char *skip,
+                                  const typename Traits<DT>::afrag *__restrict__ wp, int ksteps,
+                                  const float *__restrict__ scale, const float *__restrict__ shift,
+                                  const int (&vmask)[Geo<DT>::NT], int wave, int lane)
+{
+    typedef Traits<DT> Tr;
+    typedef Geo<DT> G;
+    typedef typename Tr::afrag afrag;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[G::NT];
+#pragma unroll
+    for (int ct = 0; ct < G::NT; ct++)
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            acc[ct][i] = 0.0f;
+
+    // A fragments of this wave: index ((tap*ksteps + ks)*OCT + wave)*64 + lane
+    const afrag *wq = wp + wave * 64 + lane;
+    const int total = 9 * ksteps;
+    afrag a0 = wq[0];
+    afrag a1 = wq[(total > 1 ? 1 : 0) * (OCT * 64)];
+    int step = 0;
+    for (int tap = 0; tap < 9; tap++) {
+        const int drow = (tap / 3 - 1) * 7 + (tap % 3 - 1);
+        int rows[G::NT];
+#pragma unroll
+        for (int ct = 0; ct < G::NT; ct++)
+            rows[ct] = ((vmask[ct] >> tap) & 1) ? (ct * 32 + r + drow) : G::NC;
+        for (int ks = 0; ks < ksteps; ks++, step++) {
+            const int nxt = step + 2 < total ? step + 2 : total - 1;
+            afrag a2 = wq[(size_t)nxt * (OCT * 64)];
+            const int u = (DT == AZH_DTYPE_F32) ? (2 * ks + h) : (2 * ks + h);
+#pragma unroll
+            for (int ct = 0; ct < G::NT; ct++) {
+                const afrag b = *reinterpret_cast<const afrag *>(in + unit_off<DT>(rows[ct], u));
+                acc[ct] = Tr::mfma(a0, b, acc[ct]);
+            }
+            a0 = a1;
+            a1 = a2;
+        }
+    }
+
+    // epilogue: bn, (+skip), relu, convert, write [cell][channel]
+    float sc[16], sh[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int ch = 32 * wave + 8 * q + 4 * h;
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(scale + ch);
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift + ch);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            sc[4 * q + i] = s4[i];
+            sh[4 * q + i] = t4[i];
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < G::NT; ct++) {
+        const int cell = ct * 32 + r;
+        if (cell < G::NC) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ch = 32 * wave + 8 * q + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    v[i] = __builtin_fmaf(acc[ct][4 * q + i], sc[4 * q + i], sh[4 * q + i]);
+                if constexpr (DT == AZH_DTYPE_F32) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int off = unit_off<DT>(cell, ch + i);
+                        if (skip)
+                            v[i] += *reinterpret_cast<const float *>(skip + off);
+                        *reinterpret_cast<float *>(out + off) = v[i] > 0.0f ? v[i] : 0.0f;
+                    }
+                } else {
+                    typedef typename Tr::quad quad;
+                    const int off = unit_off<DT>(cell, ch >> 3) + ((ch & 7) << 1);
+                    if (skip) {
+                        const quad s = *reinterpret_cast<const quad *>(skip + off);
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            v[i] += (float)s[i];
+                    }
+                    quad o;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        o[i] = (typename Tr::elem)(v[i] > 0.0f ? v[i] : 0.0f);
+                    *reinterpret_cast<quad *>(out + off) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(NTHREADS, 1) void k_tower(TowerArgs A)
+{
+    typedef Traits<DT> Tr;
+    typedef Geo<DT> G;
+    typedef typename Tr::afrag afrag;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = A.count ? *A.count : A.n;
+    const int tile0 = blockIdx.x * G::BOARDS;
+    if (tile0 >= n)
+        return;
+    const int nb = (n - tile0) < G::BOARDS ? (n - tile0) : G::BOARDS;
+
+    unsigned char *buf0 = smem;
+    unsigned char *buf1 = smem + G::IMG;
+    float *vcell = reinterpret_cast<float *>(smem + G::STAGE_OFF);
+
+    // zero both images (zero row, pad channels of the input planes, unused boards)
+    for (int i = tid * 16; i < 2 * G::IMG; i += NTHREADS * 16)
+        *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // input planes (cpp/self_play_client.cpp:174-202): ones, mover, opponent, blockers
+    for (int cell = tid; cell < nb * 49; cell += NTHREADS) {
+        const int bl = cell / 49, c = cell % 49;
+        const int x = c / 7, y = c % 7;
+        const int sq = x + 7 * (6 - y);
+        const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
+        const unsigned long long mover = A.boards[2 * (size_t)game + 0];
+        const unsigned long long opp = A.boards[2 * (size_t)game + 1];
+        const float f1 = (float)((mover >> sq) & 1ULL), f2 = (float)((opp >> sq) & 1ULL);
+        const float f3 = (float)((A.blockers >> sq) & 1ULL);
+        if constexpr (DT == AZH_DTYPE_F32) {
+            *reinterpret_cast<float *>(buf0 + unit_off<DT>(cell, 0)) = 1.0f;
+            *reinterpret_cast<float *>(buf0 + unit_off<DT>(cell, 1)) = f1;
+            *reinterpret_cast<float *>(buf0 + unit_off<DT>(cell, 2)) = f2;
+            *reinterpret_cast<float *>(buf0 + unit_off<DT>(cell, 3)) = f3;
+        } else {
+            typename Tr::quad o;
+            o[0] = (typename Tr::elem)1.0f;
+            o[1] = (typename Tr::elem)f1;
+            o[2] = (typename Tr::elem)f2;
+            o[3] = (typename Tr::elem)f3;
+            *reinterpret_cast<typename Tr::quad *>(buf0 + unit_off<DT>(cell, 0)) = o;
+        }
+    }
+
+    // per column tile: which of the 9 taps stay on the board for this lane's cell
+    int vmask[G::NT];
+    {
+        const int r = lane & 31;
+#pragma unroll
+        for (int ct = 0; ct < G::NT; ct++) {
+            const int cell = ct * 32 + r;
+            int m = 0;
+            if (cell < G::NC) {
+                const int c = cell % 49, x = c / 7, y = c % 7;
+                for (int tap = 0; tap < 9; tap++) {
+                    const int xx = x + tap / 3 - 1, yy = y + tap % 3 - 1;
+                    if (xx >= 0 && xx < 7 && yy >= 0 && yy < 7)
+                        m |= 1 << tap;
+                }
+            }
+            vmask[ct] = m;
+        }
+    }
+    __syncthreads();
+
+    // tower
+    const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w);
+    const size_t l0 = (size_t)9 * G::KSTEPS_IN * OCT * 64;
+    const size_t lf = (size_t)9 * G::KSTEPS_FULL * OCT * 64;
+    conv_layer<DT>(buf0, buf1, nullptr, wp, G::KSTEPS_IN, A.scale, A.shift, vmask, wave, lane);
+    __syncthreads();
+    wp += l0;
+    for (int b = 0; b < A.blocks; b++) {
+        const float *s1 = A.scale + (size_t)(1 + 2 * b) * F, *t1 = A.shift + (size_t)(1 + 2 * b) * F;
+        conv_layer<DT>(buf1, buf0, nullptr, wp, G::KSTEPS_FULL, s1, t1, vmask, wave, lane);
+        __syncthreads();
+        wp += lf;
+        conv_layer<DT>(buf0, buf1, buf1, wp, G::KSTEPS_FULL, s1 + F, t1 + F, vmask, wave, lane);
+        __syncthreads();
+        wp += lf;
+    }
+
+    // heads: one 32-row A tile = 17 policy channels + the value conv channel (row 17);
+    // column tiles are dealt round-robin to the waves; logits are staged in buf0.
+    {
+        const afrag *hp = reinterpret_cast<const afrag *>(A.head_w) + lane;
+        const int r = lane & 31, h = lane >> 5;
+        float *stage = reinterpret_cast<float *>(buf0);
+        for (int ct = wave; ct < G::NT; ct += OCT) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                acc[i] = 0.0f;
+            const int cell = ct * 32 + r;
+            const int row = cell < G::NC ? cell : G::NC;
+            for (int ks = 0; ks < G::KSTEPS_FULL; ks++) {
+                const afrag a = hp[(size_t)ks * 64];
+                const afrag bfrag = *reinterpret_cast<const afrag *>(buf1 + unit_off<DT>(row, 2 * ks + h));
+                acc = Tr::mfma(a, bfrag, acc);
+            }
+            if (cell < G::NC) {
+                const int bl = cell / 49, c = cell % 49;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int oc = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (oc < 17)
+                        stage[bl * 833 + 17 * c + oc] = acc[i];
+                    else if (oc == 17)
+                        vcell[cell] = acc[i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int bl = 0; bl < nb; bl++) {
+        const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
+        const float *src = reinterpret_cast<const float *>(buf0) + bl * 833;
+        float *dst = A.logits + (size_t)game * 833;
+        for (int k = tid; k < 833; k += NTHREADS)
+            dst[k] = src[k];
+    }
+    if (tid < nb) {
+        const int game = A.list ? A.list[tile0 + tid] : (tile0 + tid);
+        float s = 0.0f;
+        for (int c = 0; c < 49; c++)
+            s = __builtin_fmaf(vcell[tid * 49 + c], A.fc_w[c], s);
+        A.values[game] = tanhf(s + A.fc_b);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+static inline uint16_t f32_to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u)
+        return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+static inline uint16_t f32_to_f16(float f)
+{
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+template <typename T> static inline T cvt_elem(float f, int dt);
+template <> inline uint16_t cvt_elem<uint16_t>(float f, int dt) { return dt == AZH_DTYPE_BF16 ? f32_to_bf16(f) : f32_to_f16(f); }
+template <> inline float cvt_elem<float>(float f, int) { return f; }
+
+// Pack W[tap][cin][128] (HWIO, tap = 3*i + j) into A-fragment order.
+template <typename T>
+static void pack_conv(const float *w, int cin, int taps, int ksteps, int kstep, int octiles, int ocols,
+                      int dt, std::vector<T> &out)
+{
+    const int per_lane = kstep / 2;  // k elements per lane per MFMA
+    for (int tap = 0; tap < taps; tap++)
+        for (int ks = 0; ks < ksteps; ks++)
+            for (int ot = 0; ot < octiles; ot++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < per_lane; e++) {
+                        const int c = kstep * ks + per_lane * (lane >> 5) + e;
+                        const int oc = 32 * ot + (lane & 31);
+                        float v = 0.0f;
+                        if (c < cin && oc < ocols)
+                            v = w[((size_t)tap * cin + c) * ocols + oc];
+                        out.push_back(cvt_elem<T>(v, dt));
+                    }
+}
+
+struct NetDtypeBuffers {
+    void *conv_w = nullptr;
+    void *head_w = nullptr;
+};
+
+}  // namespace azh
+
+using namespace azh;
+
+struct azh_net {
+    int blocks = 0, filters = 0;
+    std::vector<float> conv_flat;  // host copy, reference order
+    float *d_scale = nullptr, *d_shift = nullptr, *d_fcw = nullptr;
+    float fc_b = 0.0f;
+    NetDtypeBuffers bufs[3];
+};
+
+static int net_pack(azh_net *net, int dt)
+{
+    if (net->bufs[dt].conv_w)
+        return 0;
+    const int B = net->blocks;
+    const float *p = net->conv_flat.data();
+    const int kstep = dt == AZH_DTYPE_F32 ? 2 : 16;
+    const int ks_in = dt == AZH_DTYPE_F32 ? 2 : 1;
+    const int ks_full = F / kstep;
+    const size_t head_off = (size_t)9 * 4 * F + (size_t)2 * B * 9 * F * F;
+    // fused head matrix [128][32]: columns 0..16 policy, 17 value conv
+    std::vector<float> head((size_t)F * 32, 0.0f);
+    for (int c = 0; c < F; c++) {
+        for (int t = 0; t < 17; t++)
+            head[(size_t)c * 32 + t] = p[head_off + (size_t)c * 17 + t];
+        head[(size_t)c * 32 + 17] = p[head_off + (size_t)F * 17 + c];
+    }
+    auto upload = [&](const void *src, size_t bytes, void **dst) -> int {
+        AZH_HIP(hipMalloc(dst, bytes));
+        AZH_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (dt == AZH_DTYPE_F32) {
+        std::vector<float> cw, hw;
+        pack_conv<float>(p, 4, 9, ks_in, kstep, OCT, F, dt, cw);
+        for (int l = 0; l < 2 * B; l++)
+            pack_conv<float>(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, F, 9, ks_full, kstep, OCT, F, dt, cw);
+        pack_conv<float>(head.data(), F, 1, ks_full, kstep, 1, 32, dt, hw);
+        if (upload(cw.data(), cw.size() * 4, &net->bufs[dt].conv_w)) return -1;
+        if (upload(hw.data(), hw.size() * 4, &net->bufs[dt].head_w)) return -1;
+    } else {
+        std::vector<uint16_t> cw, hw;
+        pack_conv<uint16_t>(p, 4, 9, ks_in, kstep, OCT, F, dt, cw);
+        for (int l = 0; l < 2 * B; l++)
+            pack_conv<uint16_t>(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, F, 9, ks_full, kstep, OCT, F, dt, cw);
+        pack_conv<uint16_t>(head.data(), F, 1, ks_full, kstep, 1, 32, dt, hw);
+        if (upload(cw.data(), cw.size() * 2, &net->bufs[dt].conv_w)) return -1;
+        if (upload(hw.data(), hw.size() * 2, &net->bufs[dt].head_w)) return -1;
+    }
+    return 0;
+}
+
+extern "C" int azh_net_create(int blocks, int filters, const float *conv_flat, const float *bn_flat,
+                              float bn_eps, azh_net **out)
+{
+    if (!out || !conv_flat || !bn_flat)
+        return azh_fail(-1, "azh_net_create: null argument");
+    if (filters != F)
+        return azh_fail(-2, "azh_net_create: this build supports filters == 128 (model.py:16), got %d", filters);
+    if (blocks < 0 || blocks > 64)
+        return azh_fail(-2, "azh_net_create: bad block count %d", blocks);
+    if (azh_require_device())
+        return -3;
+    azh_net *net = new azh_net();
+    net->blocks = blocks;
+    net->filters = filters;
+    const size_t n_conv = (size_t)9 * 4 * F + (size_t)2 * blocks * 9 * F * F + (size_t)F * 17 + F + 49 + 1;
+    net->conv_flat.assign(conv_flat, conv_flat + n_conv);
+    const int nbn = 2 * blocks + 1;
+    std::vector<float> scale((size_t)nbn * F), shift((size_t)nbn * F);
+    for (int l = 0; l < nbn; l++)
+        for (int c = 0; c < F; c++) {
+            const float mean = bn_flat[((size_t)2 * l) * F + c], var = bn_flat[((size_t)2 * l + 1) * F + c];
+            const double inv = 1.0 / sqrt((double)var + (double)bn_eps);
+            scale[(size_t)l * F + c] = (float)inv;
+            shift[(size_t)l * F + c] = (float)(-(double)mean * inv);
+        }
+    const float *fc = conv_flat + n_conv - 50;
+    net->fc_b = fc[49];
+    AZH_HIP(hipMalloc((void **)&net->d_scale, scale.size() * 4));
+    AZH_HIP(hipMalloc((void **)&net->d_shift, shift.size() * 4));
+    AZH_HIP(hipMalloc((void **)&net->d_fcw, 49 * 4));
+    AZH_HIP(hipMemcpy(net->d_scale, scale.data(), scale.size() * 4, hipMemcpyHostToDevice));
+    AZH_HIP(hipMemcpy(net->d_shift, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
+    AZH_HIP(hipMemcpy(net->d_fcw, fc, 49 * 4, hipMemcpyHostToDevice));
+    *out = net;
+    return 0;
+}
+
+extern "C" void azh_net_destroy(azh_net *net)
+{
+    if (!net)
+        return;
+    for (auto &b : net->bufs) {
+        if (b.conv_w) (void)hipFree(b.conv_w);
+        if (b.head_w) (void)hipFree(b.head_w);
+    }
+    if (net->d_scale) (void)hipFree(net->d_scale);
+    if (net->d_shift) (void)hipFree(net->d_shift);
+    if (net->d_fcw) (void)hipFree(net->d_fcw);
+    delete net;
+}
+
+template <int DT> static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
+{
+    typedef Geo<DT> G;
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZH_HIP(hipFuncSetAttribute((const void *)k_tower<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr_set = true;
+    }
+    const int grid = (max_n + G::BOARDS - 1) / G::BOARDS;
+    if (grid <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_tower<DT>, dim3(grid), dim3(NTHREADS), G::LDS_BYTES, stream, args);
+    AZH_HIP(hipGetLastError());
+    return 0;
+}
+
+// Evaluate up to max_n boards (dense list `list`/`count` on the device, or the
+// first n boards when both are null).  Everything is indexed by game.
+int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
+                   const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
+                   float *d_values, hipStream_t stream)
+{
+    if (dtype < 0 || dtype > 2)
+        return azh_fail(-2, "bad dtype %d", dtype);
+    if (net_pack(net, dtype))
+        return -1;
+    TowerArgs a;
+    a.conv_w = net->bufs[dtype].conv_w;
+    a.head_w = net->bufs[dtype].head_w;
+    a.scale = net->d_scale;
+    a.shift = net->d_shift;
+    a.fc_w = net->d_fcw;
+    a.fc_b = net->fc_b;
+    a.blocks = net->blocks;
+    a.boards = d_boards;
+    a.list = d_list;
+    a.count = d_count;
+    a.n = max_n;
+    a.blockers = blockers;
+    a.logits = d_logits;
+    a.values = d_values;
+    switch (dtype) {
+    case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32>(a, max_n, stream);
+    case AZH_DTYPE_BF16: return launch_tower<AZH_DTYPE_BF16>(a, max_n, stream);
+    default: return launch_tower<AZH_DTYPE_F16>(a, max_n, stream);
+    }
+}
+
+extern "C" int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards,
+                               uint64_t blockers, float *logits_out, float *values_out)
+{
+    if (!net || !leaf_boards || !logits_out || !values_out || n < 0)
+        return azh_fail(-1, "azh_net_forward: bad argument");
+    if (n == 0)
+        return 0;
+    unsigned long long *d_b = nullptr;
+    float *d_l = nullptr, *d_v = nullptr;
+    AZH_HIP(hipMalloc((void **)&d_b, (size_t)n * 16));
+    AZH_HIP(hipMalloc((void **)&d_l, (size_t)n * 833 * 4));
+    AZH_HIP(hipMalloc((void **)&d_v, (size_t)n * 4));
+    AZH_HIP(hipMemcpy(d_b, leaf_boards, (size_t)n * 16, hipMemcpyHostToDevice));
+    int rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, blockers, d_l, d_v, 0);
+    if (rc == 0) {
+        AZH_HIP(hipDeviceSynchronize());
+        AZH_HIP(hipMemcpy(logits_out, d_l, (size_t)n * 833 * 4, hipMemcpyDeviceToHost));
+        AZH_HIP(hipMemcpy(values_out, d_v, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_b);
+    (void)hipFree(d_l);
+    (void)hipFree(d_v);
+    return rc;
+}

@@ -1,0 +1,355 @@
+"""ctypes binding of libataxxzero_hip.so (include/ataxxzero_hip.h).
+
+Mirror of the reference's link.py (link.py:6-32): the same four module-level
+callables — launch_threads, get_workload, complete_workload, shutdown — with the
+same argument order, bound to the GPU library instead of
+./cpp/self_play_client.so, plus the `azh_*` device-resident entry points.
+
+There is no CPU fallback: if the library is missing it is built with hipcc; if
+no MI355X is visible every compute call raises AzhError.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+POLICY_SIZE = 833
+FEATURE_SIZE = 196
+MAX_MOVES = 256
+STAT_COUNT = 16
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16,
+          "f16": DTYPE_F16, "fp16": DTYPE_F16}
+LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
+STAT_NAMES = ["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
+              "edge_overflow", "reroot_nodes", "reroot_edges", "ring_overflow"]
+
+
+class AzhError(RuntimeError):
+    pass
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("games", ctypes.c_int32), ("visits", ctypes.c_int32), ("max_plies", ctypes.c_int32),
+                ("edges_per_node", ctypes.c_int32), ("c_puct", ctypes.c_float),
+                ("dirichlet_alpha", ctypes.c_float), ("dirichlet_weight", ctypes.c_float),
+                ("start_turn", ctypes.c_int32), ("seed", ctypes.c_uint64), ("start_x", ctypes.c_uint64),
+                ("start_o", ctypes.c_uint64), ("blockers", ctypes.c_uint64)]
+
+
+class GameState(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("phase", "arena", "n_nodes", "n_edges", "ply", "root_visits",
+                                              "leaf_kind", "leaf_node", "path_len")] + [("uid", ctypes.c_uint32)]
+
+    def as_tuple(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("select_ms", ctypes.c_double), ("net_ms", ctypes.c_double), ("backup_ms", ctypes.c_double),
+                ("iterations", ctypes.c_int64), ("net_evals", ctypes.c_int64)]
+
+
+_vp, _i32, _u64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_float
+_P = ctypes.POINTER
+
+# name -> (restype, argtypes); every symbol include/ataxxzero_hip.h declares
+SIGNATURES = {
+    "azh_last_error": (ctypes.c_char_p, []),
+    "azh_device_count": (ctypes.c_int, []),
+    "azh_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "azh_perft": (ctypes.c_int, [_u64, _u64, _u64, ctypes.c_int, ctypes.c_int, _P(_u64)]),
+    "azh_rules_batch": (ctypes.c_int, [ctypes.c_int, _vp, _u64, _vp, _vp, _vp]),
+    "azh_makemove_batch": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp]),
+    "azh_features_batch": (ctypes.c_int, [ctypes.c_int, _vp, _u64, _vp]),
+    "azh_random_play": (ctypes.c_int, [ctypes.c_int, _u64, _u64, _u64, _u64, ctypes.c_int, ctypes.c_int,
+                                       _vp, _vp, _vp, _vp]),
+    "azh_probe_detmath": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _u64, _vp]),
+    "azh_net_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _f32, _P(_vp)]),
+    "azh_net_destroy": (None, [_vp]),
+    "azh_net_forward": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
+    "azh_engine_create": (ctypes.c_int, [_P(Config), _P(_vp)]),
+    "azh_engine_destroy": (None, [_vp]),
+    "azh_engine_node_cap": (ctypes.c_int, [_vp]),
+    "azh_engine_edge_cap": (ctypes.c_int, [_vp]),
+    "azh_engine_select": (ctypes.c_int, [_vp, _P(_i32)]),
+    "azh_engine_leaves": (ctypes.c_int, [_vp, _vp, _vp]),
+    "azh_engine_leaf_features": (ctypes.c_int, [_vp, _vp, _vp]),
+    "azh_engine_eval": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    "azh_engine_set_evals": (ctypes.c_int, [_vp, _vp, _vp]),
+    "azh_engine_backup": (ctypes.c_int, [_vp]),
+    "azh_engine_run": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "azh_engine_sync": (ctypes.c_int, [_vp]),
+    "azh_engine_game_state": (ctypes.c_int, [_vp, ctypes.c_int, _P(GameState)]),
+    "azh_engine_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "azh_engine_stats": (ctypes.c_int, [_vp, _vp]),
+    "azh_engine_timing_reset": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "azh_engine_timing": (ctypes.c_int, [_vp, _P(Timing)]),
+    "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
+    # the reference's ABI, link.py:8-32
+    "launch_threads": (None, [ctypes.c_char_p, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "get_workload": (ctypes.c_int, []),
+    "complete_workload": (None, [ctypes.c_int, _vp, _vp]),
+    "shutdown": (None, []),
+}
+
+_dll = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building first if needed) the HIP library and type its symbols."""
+    global _dll
+    if _dll is not None:
+        return _dll
+    path = _build.build()
+    dll = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(dll, name)
+        fn.restype = res
+        fn.argtypes = args
+    _dll = dll
+    return dll
+
+
+def check(rc):
+    if rc != 0:
+        raise AzhError("ataxxzero_hip error %d: %s" % (rc, load().azh_last_error().decode(errors="replace")))
+
+
+def device_count():
+    n = load().azh_device_count()
+    return max(n, 0)
+
+
+def require_gpu():
+    n = load().azh_device_count()
+    if n <= 0:
+        raise AzhError("no MI355X / HIP device visible (azh_device_count = %d: %s); this package has no CPU "
+                       "fallback" % (n, load().azh_last_error().decode(errors="replace")))
+    return n
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+# ------------------------------------------------------------------ reference ABI (link.py:8-32)
+
+def launch_threads(output_path, visits, fill_buffer1, fill_buffer2, buffer_entries, thread_count):
+    load().launch_threads(output_path, visits, fill_buffer1, fill_buffer2, buffer_entries, thread_count)
+
+
+def get_workload():
+    return load().get_workload()
+
+
+def complete_workload(workload, posteriors, values):
+    load().complete_workload(workload, posteriors, values)
+
+
+def shutdown():
+    load().shutdown()
+
+
+# ------------------------------------------------------------------ rules
+
+def pack_board(x, o, turn):
+    return np.array([int(x) | (int(turn) << 63), int(o)], dtype=np.uint64)
+
+
+def perft(x, o, blockers, turn, depth):
+    out = ctypes.c_uint64(0)
+    check(load().azh_perft(int(x), int(o), int(blockers), int(turn), int(depth), ctypes.byref(out)))
+    return int(out.value)
+
+
+def rules_batch(boards, blockers):
+    boards = np.ascontiguousarray(boards, dtype=np.uint64).reshape(-1, 2)
+    n = len(boards)
+    moves = np.zeros((n, MAX_MOVES), dtype=np.uint16)
+    counts = np.zeros(n, dtype=np.int32)
+    results = np.zeros(n, dtype=np.int32)
+    check(load().azh_rules_batch(n, _ptr(boards), int(blockers), _ptr(moves), _ptr(counts), _ptr(results)))
+    return moves, counts, results
+
+
+def makemove_batch(boards, moves):
+    boards = np.ascontiguousarray(boards, dtype=np.uint64).reshape(-1, 2)
+    moves = np.ascontiguousarray(moves, dtype=np.uint16)
+    out = np.zeros_like(boards)
+    check(load().azh_makemove_batch(len(boards), _ptr(boards), _ptr(moves), _ptr(out)))
+    return out
+
+
+def features_batch(leaf_boards, blockers):
+    leaf_boards = np.ascontiguousarray(leaf_boards, dtype=np.uint64).reshape(-1, 2)
+    out = np.zeros((len(leaf_boards), 7, 7, 4), dtype=np.float32)
+    check(load().azh_features_batch(len(leaf_boards), _ptr(leaf_boards), int(blockers), _ptr(out)))
+    return out
+
+
+def random_play(n_games, seed, x, o, blockers, turn, max_plies=400, trace=True):
+    plies = np.zeros(n_games, dtype=np.int32)
+    results = np.zeros(n_games, dtype=np.int32)
+    boards = np.zeros((n_games, max_plies, 2), dtype=np.uint64) if trace else None
+    moves = np.zeros((n_games, max_plies), dtype=np.uint16) if trace else None
+    check(load().azh_random_play(n_games, int(seed), int(x), int(o), int(blockers), int(turn), max_plies,
+                                 _ptr(plies), _ptr(results), _ptr(boards), _ptr(moves)))
+    return plies, results, boards, moves
+
+
+def probe_detmath(kind, values=None, aux=None, seed=0):
+    values = None if values is None else np.ascontiguousarray(values, dtype=np.float32)
+    aux = None if aux is None else np.ascontiguousarray(aux, dtype=np.uint32)
+    n = len(values) if kind in (0, 1) else len(aux)
+    out = np.zeros(4 * n if kind == 3 else n, dtype=np.uint32)
+    check(load().azh_probe_detmath(kind, n, _ptr(values), _ptr(aux), int(seed), _ptr(out)))
+    return out
+
+
+# ------------------------------------------------------------------ network
+
+class Net:
+    """Device-resident policy/value net (model.Network forward, model.py:38-79)."""
+
+    def __init__(self, conv_weights, bn_params, bn_eps=1e-3):
+        blocks = (len(conv_weights) - 5) // 2
+        filters = int(conv_weights[0].shape[-1])
+        if len(conv_weights) != 2 * blocks + 5 or len(bn_params) != 2 * (2 * blocks + 1):
+            raise ValueError("weight lists do not match model.py's layout (2B+5 / 2(2B+1) arrays)")
+        conv_flat = np.concatenate([np.asarray(a, dtype=np.float32).ravel() for a in conv_weights])
+        bn_flat = np.concatenate([np.asarray(a, dtype=np.float32).ravel() for a in bn_params])
+        self.blocks, self.filters = blocks, filters
+        h = ctypes.c_void_p()
+        check(load().azh_net_create(blocks, filters, _ptr(conv_flat), _ptr(bn_flat), bn_eps, ctypes.byref(h)))
+        self.h = h
+
+    def forward(self, leaf_boards, blockers, dtype=DTYPE_BF16):
+        leaf_boards = np.ascontiguousarray(leaf_boards, dtype=np.uint64).reshape(-1, 2)
+        n = len(leaf_boards)
+        logits = np.zeros((n, 7, 7, 17), dtype=np.float32)
+        values = np.zeros((n, 1), dtype=np.float32)
+        check(load().azh_net_forward(self.h, dtype, n, _ptr(leaf_boards), int(blockers), _ptr(logits), _ptr(values)))
+        return logits, values
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().azh_net_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ engine
+
+class Engine:
+    """Batched self-play search on the GPU (cpp/self_play_client.cpp's workers)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.G = cfg.games
+        h = ctypes.c_void_p()
+        check(load().azh_engine_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+        self.node_cap = load().azh_engine_node_cap(h)
+        self.edge_cap = load().azh_engine_edge_cap(h)
+        self._json = np.zeros(1 << 22, dtype=np.uint8)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().azh_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def select(self):
+        n = ctypes.c_int32(0)
+        check(load().azh_engine_select(self.h, ctypes.byref(n)))
+        return int(n.value)
+
+    def leaves(self):
+        need = np.zeros(self.G, dtype=np.int32)
+        boards = np.zeros((self.G, 2), dtype=np.uint64)
+        check(load().azh_engine_leaves(self.h, _ptr(need), _ptr(boards)))
+        return need, boards
+
+    def leaf_features(self, n):
+        out = np.zeros((max(n, 1), 7, 7, 4), dtype=np.float32)
+        games = np.zeros(max(n, 1), dtype=np.int32)
+        check(load().azh_engine_leaf_features(self.h, _ptr(out), _ptr(games)))
+        return out[:n], games[:n]
+
+    def eval(self, net, dtype=DTYPE_BF16):
+        check(load().azh_engine_eval(self.h, net.h, dtype))
+
+    def set_evals(self, logits, values):
+        logits = np.ascontiguousarray(logits, dtype=np.float32).reshape(self.G, POLICY_SIZE)
+        values = np.ascontiguousarray(values, dtype=np.float32).reshape(self.G)
+        check(load().azh_engine_set_evals(self.h, _ptr(logits), _ptr(values)))
+
+    def backup(self):
+        check(load().azh_engine_backup(self.h))
+
+    def run(self, net, iterations, dtype=DTYPE_BF16):
+        check(load().azh_engine_run(self.h, net.h, dtype, iterations))
+
+    def sync(self):
+        check(load().azh_engine_sync(self.h))
+
+    def game_state(self, g):
+        s = GameState()
+        check(load().azh_engine_game_state(self.h, g, ctypes.byref(s)))
+        return s
+
+    def tree(self, g):
+        s = self.game_state(g)
+        boards = np.zeros((s.n_nodes, 2), dtype=np.uint64)
+        info = np.zeros((s.n_nodes, 4), dtype=np.uint32)
+        edges = np.zeros((s.n_edges, 4), dtype=np.uint32)
+        moves = np.zeros(s.n_edges, dtype=np.uint16)
+        check(load().azh_engine_tree(self.h, g, _ptr(boards), _ptr(info), _ptr(edges), _ptr(moves)))
+        return boards, info, edges, moves
+
+    def stats(self):
+        out = np.zeros(STAT_COUNT, dtype=np.uint64)
+        check(load().azh_engine_stats(self.h, _ptr(out)))
+        return {n: int(out[i]) for i, n in enumerate(STAT_NAMES)}
+
+    def timing_reset(self, enable=True):
+        check(load().azh_engine_timing_reset(self.h, 1 if enable else 0))
+
+    def timing(self):
+        t = Timing()
+        check(load().azh_engine_timing(self.h, ctypes.byref(t)))
+        return {"select_ms": t.select_ms, "net_ms": t.net_ms, "backup_ms": t.backup_ms, "iterations": t.iterations}
+
+    def drain_json(self):
+        """Finished games since the last call, as a list of JSON lines (bytes, no newline)."""
+        lines = []
+        while True:
+            used = ctypes.c_int64(0)
+            n = ctypes.c_int32(0)
+            rc = load().azh_engine_drain_json(self.h, _ptr(self._json), self._json.nbytes, ctypes.byref(used),
+                                              ctypes.byref(n))
+            if rc == -6:
+                self._json = np.zeros(self._json.nbytes * 2, dtype=np.uint8)
+                continue
+            check(rc)
+            if n.value == 0:
+                break
+            lines.extend(bytes(self._json[:used.value]).split(b"\n")[:-1])
+        return lines

@@ -1,0 +1,203 @@
+/*
+ * ataxxzero_hip.h — C ABI of the MI355X-native batched Ataxx self-play engine.
+ *
+ * Drop-in boundary for the reference's self-play hot path.  Plain C types only
+ * (pointers, sizes, ints); no torch / Python objects cross this line.  All
+ * `azh_*` functions return 0 on success and a negative code on failure, with a
+ * message available from azh_last_error().  Host pointers are caller-owned and
+ * are fully consumed (copied) before the call returns unless stated otherwise.
+ *
+ * Each entry point names the reference interface it replaces (file:line under
+ * /root/reference).  The binding a maintainer of the reference would add is in
+ * INTEGRATION.md; the Python side of this repo binds it in ataxxzero_amd/link.py.
+ *
+ * Bit conventions (cpp/bitboards.hpp:9-25, cpp/ataxx.hpp:28-34): square =
+ * file + 7*rank0, a1 = bit 0.  A packed board is two u64: word0 = x stones with
+ * the side to move in bit 63 (0 = x, 1 = o), word1 = o stones.  A "leaf board"
+ * is (mover stones, opponent stones).  A move is u16 = from | to << 8, clone
+ * <=> from == to (cpp/move.hpp:9-33).  Policy rows are the reference's
+ * (7,7,17) f32 logits, flat index 119*to_x + 17*to_y + layer
+ * (cpp/self_play_client.cpp:220-237); feature rows are (7,7,4) f32
+ * (cpp/self_play_client.cpp:174-202).
+ */
+#ifndef ATAXXZERO_HIP_H
+#define ATAXXZERO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZH_POLICY_SIZE 833
+#define AZH_FEATURE_SIZE 196
+#define AZH_MAX_MOVES 256
+#define AZH_STAT_COUNT 16
+
+enum { AZH_DTYPE_F32 = 0, AZH_DTYPE_BF16 = 1, AZH_DTYPE_F16 = 2 };
+enum { AZH_LEAF_NONE = 0, AZH_LEAF_EVAL = 1, AZH_LEAF_TERMINAL = 2, AZH_LEAF_ROOT = 3 };
+
+/* ------------------------------------------------------------------ errors */
+const char *azh_last_error(void);
+/* number of visible HIP devices, or a negative code when the runtime is unusable */
+int azh_device_count(void);
+/* select the device used by every later call from this process (one process per GPU) */
+int azh_set_device(int device);
+
+/* ------------------------------------------------------------------ rules
+ * Replaces cpp/movegen.cpp:10-79 (movegen), cpp/makemove.cpp:56-76 (makemove),
+ * cpp/self_play_client.cpp:109-144 (get_board_result) and perft.py:5-26. */
+
+/* perft node count on the GPU with perft.py's "a position without a move has one
+ * pass child" semantics. */
+int azh_perft(uint64_t x, uint64_t o, uint64_t blockers, int turn, int depth, uint64_t *nodes_out);
+
+/* For n packed boards: legal moves in the reference's movegen order
+ * (moves_out [n][AZH_MAX_MOVES]), their count, and the adjudication
+ * 0 / 1 / 2.  Any output pointer may be NULL. */
+int azh_rules_batch(int n, const uint64_t *boards, uint64_t blockers, uint16_t *moves_out,
+                    int32_t *counts_out, int32_t *results_out);
+
+/* boards_out[i] = makemove(boards[i], moves[i]); a move of 0xFFFF passes
+ * (ataxx_rules.py:112-114). */
+int azh_makemove_batch(int n, const uint64_t *boards, const uint16_t *moves, uint64_t *boards_out);
+
+/* Reference feature rows (cpp/self_play_client.cpp:174-202, engine.py:53-73) for n
+ * leaf boards (mover, opponent): out [n][7][7][4] f32. */
+int azh_features_batch(int n, const uint64_t *leaf_boards, uint64_t blockers, float *out);
+
+/* Uniform-random playouts (generate_games.py:16-75 with --random-play): plays
+ * n_games games from the given start to the end or max_plies.  Outputs, all
+ * optional: plies[n], results[n] (0 = unfinished), and the per-ply trace
+ * boards_out [n][max_plies][2] (x, o), moves_out [n][max_plies]. */
+int azh_random_play(int n_games, uint64_t seed, uint64_t x, uint64_t o, uint64_t blockers, int turn,
+                    int max_plies, int32_t *plies, int32_t *results, uint64_t *boards_out,
+                    uint16_t *moves_out);
+
+/* Test hook for the engine's deterministic f32 math / Philox4x32-10 (the arithmetic
+ * the search's bit-exact contract with the CPU oracle rests on).  kind 0: exp(in[i]);
+ * 1: log(in[i]); 2: gamma(alpha = in[0]) keyed (seed, aux[3i..3i+2] = uid, ply, edge);
+ * 3: philox(seed; aux[4i..4i+3]) -> out[4i..4i+3].  out holds raw 32-bit patterns. */
+int azh_probe_detmath(int kind, int n, const float *in, const uint32_t *aux, uint64_t seed, uint32_t *out);
+
+/* ------------------------------------------------------------------ network
+ * Replaces model.Network's forward pass (model.py:38-79,116-142) and
+ * model.load_model (model.py:186-196). */
+typedef struct azh_net azh_net;
+
+/* conv_flat: the 2*blocks+5 parameter arrays of the .npy file's first list,
+ * concatenated in file order: (3,3,4,F), 2*blocks x (3,3,F,F), (1,1,F,17),
+ * (1,1,F,1), fc_w (49,1), fc_b (1,).  bn_flat: the 2*(2*blocks+1) arrays of the
+ * second list, (moving_mean, moving_variance) per batch-norm in creation order.
+ * gamma = 1, beta = 0 as after model.load_model;
+ * bn_eps is TensorFlow's default 1e-3. */
+int azh_net_create(int blocks, int filters, const float *conv_flat, const float *bn_flat,
+                   float bn_eps, azh_net **out);
+void azh_net_destroy(azh_net *net);
+
+/* logits_out [n][833] f32 (raw policy logits, model.py:66-69), values_out [n]
+ * (tanh value, model.py:71-79), for n leaf boards (mover, opponent). */
+int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards, uint64_t blockers,
+                    float *logits_out, float *values_out);
+
+/* ------------------------------------------------------------------ engine
+ * Replaces the worker threads of cpp/self_play_client.cpp: MCTS::step (:419-473),
+ * Evaluations::populate (:153-272), MCTS::play (:475-492),
+ * sample_proportionally_to_visits (:495-506), generate_game (:508-582). */
+typedef struct azh_engine azh_engine;
+
+typedef struct {
+    int32_t games;           /* concurrent game slots ("threads" in the reference) */
+    int32_t visits;          /* global_visits (:46,:522) */
+    int32_t max_plies;       /* maximum_game_plies (:34) */
+    int32_t edges_per_node;  /* edge arena per game = (visits + 8) * edges_per_node */
+    float c_puct;            /* exploration_parameter (:31) */
+    float dirichlet_alpha;   /* (:32) */
+    float dirichlet_weight;  /* (:33) */
+    int32_t start_turn;
+    uint64_t seed;
+    uint64_t start_x, start_o, blockers; /* STARTING_GAME_POSITION (:23) */
+} azh_config;
+
+typedef struct {
+    int32_t phase, arena, n_nodes, n_edges, ply, root_visits, leaf_kind, leaf_node, path_len;
+    uint32_t uid;
+} azh_game_state;
+
+enum {
+    AZH_STAT_STEPS = 0, AZH_STAT_NN_EVALS, AZH_STAT_LEVELS, AZH_STAT_CHILDREN, AZH_STAT_NEW_MOVES,
+    AZH_STAT_PLIES, AZH_STAT_GAMES, AZH_STAT_DROPPED, AZH_STAT_EDGE_OVERFLOW, AZH_STAT_REROOT_NODES,
+    AZH_STAT_REROOT_EDGES, AZH_STAT_RING_OVERFLOW
+};
+
+typedef struct {
+    /* sums of HIP-event elapsed milliseconds over the launches recorded since the
+     * last azh_engine_timing_reset, and the number of iterations recorded */
+    double select_ms, net_ms, backup_ms;
+    int64_t iterations;
+    int64_t net_evals; /* leaves evaluated by the net in those iterations */
+} azh_timing;
+
+int azh_engine_create(const azh_config *cfg, azh_engine **out);
+void azh_engine_destroy(azh_engine *e);
+int azh_engine_node_cap(const azh_engine *e);
+int azh_engine_edge_cap(const azh_engine *e);
+
+/* One search iteration = select -> evaluate -> backup.
+ * select: PUCT descent + expansion in every game (one new leaf per game). */
+int azh_engine_select(azh_engine *e, int32_t *n_leaves_out);
+/* need_eval [G], leaf_boards [G][2] (mover, opponent); either may be NULL */
+int azh_engine_leaves(azh_engine *e, int32_t *need_eval, uint64_t *leaf_boards);
+/* the reference's request_evaluation role (:648-681): feature rows of the current leaf
+ * batch, dense, in game order: out [n_leaves][7][7][4] f32; games_out [n_leaves]
+ * (optional) = the game each row belongs to */
+int azh_engine_leaf_features(azh_engine *e, float *out, int32_t *games_out);
+/* evaluate the leaf batch on the device with the built-in net */
+int azh_engine_eval(azh_engine *e, azh_net *net, int dtype);
+/* or supply evaluations from outside (the reference's complete_workload role,
+ * :723-738): host arrays indexed by game, logits [G][833], values [G] */
+int azh_engine_set_evals(azh_engine *e, const float *logits, const float *values);
+/* priors (+ root Dirichlet), backup, and — once the root has `visits` visits —
+ * sample the move, record the ply, re-root, finish/restart games */
+int azh_engine_backup(azh_engine *e);
+
+/* `iterations` full iterations with the built-in net, enqueued asynchronously */
+int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations);
+int azh_engine_sync(azh_engine *e);
+
+int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out);
+/* arena dump: boards [n_nodes][2] u64, info [n_nodes][4] u32
+ * (first_edge, n_edges | result << 16, 0, terminal value bits), edges
+ * [n_edges][4] u32 (prior bits, visits, total score bits, child), moves [n_edges] */
+int azh_engine_tree(azh_engine *e, int game, uint64_t *boards, uint32_t *info, uint32_t *edges,
+                    uint16_t *moves);
+int azh_engine_stats(azh_engine *e, uint64_t *out /* [AZH_STAT_COUNT] */);
+int azh_engine_timing_reset(azh_engine *e, int enable);
+int azh_engine_timing(azh_engine *e, azh_timing *out);
+
+/* Finished games as JSON lines in the reference's format
+ * (cpp/self_play_client.cpp:512,565-578,639-641: keys boards, dists, moves,
+ * result; one compact object per line).  Writes whole lines only; *used = bytes
+ * written, *n_games = lines written; call again while *n_games > 0. */
+int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, int32_t *n_games);
+
+/* ------------------------------------------------------------------ reference ABI
+ * The four symbols link.py:6-32 binds (cpp/self_play_client.cpp:683-749), with
+ * the worker threads replaced by GPU game slots: `thread_count` concurrent
+ * games are split into two halves of `buffer_entries` leaf rows; the host
+ * evaluates a filled (buffer_entries,7,7,4) f32 buffer and hands back
+ * (buffer_entries,7,7,17) posteriors (raw logits) + (buffer_entries,1) values.
+ * (`shutdown` shadows the libc socket call of the same name exactly as the
+ * reference's library does; define AZH_NO_REFERENCE_ABI to hide these.) */
+#ifndef AZH_NO_REFERENCE_ABI
+void launch_threads(char *output_path, int visits, float *fill_buffer1, float *fill_buffer2,
+                    int buffer_entries, int thread_count);
+int get_workload(void);
+void complete_workload(int workload, float *posteriors, float *values);
+void shutdown(void);
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif

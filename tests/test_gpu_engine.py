@@ -1,0 +1,118 @@
+"""Search parity: the HIP engine against the CPU oracle (oracle/mcts_oracle.c), fed the
+same evaluator outputs, compared bit for bit: per-game state, whole tree arenas
+(boards, edge priors / visits / scores / children as raw 32-bit patterns), finished
+game records."""
+import json
+
+import numpy as np
+import pytest
+
+from ataxxzero_amd import link, model
+from oracle import oracle_lib as orc
+from tests.helpers import replay_game_entry, synthetic_evals
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(games, visits, max_plies=400, edges_per_node=96, seed=77, fen=orc.START_FEN_SELFPLAY, weight=0.25):
+    ocfg = orc.make_config(games, visits, seed=seed, fen_str=fen, max_plies=max_plies,
+                           edges_per_node=edges_per_node, weight=weight)
+    gcfg = link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_})
+    return orc.Engine(ocfg), link.Engine(gcfg)
+
+
+def compare_all(oe, ge, games):
+    for g in games:
+        so, sg = oe.game_state(g), ge.game_state(g)
+        assert so.as_tuple() == sg.as_tuple(), (g, so.as_tuple(), sg.as_tuple())
+        to, tg = oe.tree(g), ge.tree(g)
+        for name, a, b in zip(("boards", "info", "edges", "moves"), to, tg):
+            assert a.shape == b.shape and (a == b).all(), (g, name)
+
+
+def run_lockstep(oe, ge, iterations, check_every=1):
+    G = oe.G
+    o_games, g_lines = [], []
+    for it in range(iterations):
+        n_o, need_o = oe.select()
+        n_g = ge.select()
+        need_g, lb_g = ge.leaves()
+        lb_o = oe.leaf_boards()
+        assert n_o == n_g and (need_o == need_g).all(), it
+        assert (lb_o[need_o == 1] == lb_g[need_o == 1]).all(), it
+        logits, values = synthetic_evals(lb_o)
+        oe.backup(logits, values)
+        ge.set_evals(logits, values)
+        ge.backup()
+        if it % check_every == 0 or it == iterations - 1:
+            compare_all(oe, ge, range(G))
+        o_games += oe.pop_games()
+        g_lines += ge.drain_json()
+    return o_games, g_lines
+
+
+def test_engine_matches_oracle_bit_for_bit_small_visits():
+    oe, ge = make_pair(games=24, visits=12, max_plies=60, seed=5)
+    o_games, g_lines = run_lockstep(oe, ge, 900, check_every=7)
+    so, sg = oe.stats(), ge.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    assert so["plies"] > 200 and so["games"] + so["dropped"] > 3
+    o_sorted = sorted(o_games, key=lambda r: r["uid"])
+    assert len(g_lines) == len(o_sorted)
+    for line, rec in zip(g_lines, o_sorted):
+        entry = json.loads(line)
+        assert list(entry.keys()) == ["boards", "dists", "moves", "result"]  # nlohmann: sorted keys
+        assert entry == rec["entry"]
+        assert b" " not in line
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+
+
+def test_engine_matches_oracle_reference_settings():
+    # the reference's constants: 4-blocker start, Dirichlet 0.15 / 0.25, c = 1
+    oe, ge = make_pair(games=6, visits=100, seed=20260101)
+    run_lockstep(oe, ge, 450, check_every=50)
+    assert oe.stats()["plies"] >= 6
+
+
+def test_edge_arena_overflow_forces_the_move_like_the_oracle():
+    oe, ge = make_pair(games=4, visits=64, edges_per_node=8, seed=9, fen=orc.START_FEN_PLAIN)
+    run_lockstep(oe, ge, 300, check_every=10)
+    assert oe.stats()["edge_overflow"] > 0 and ge.stats()["edge_overflow"] == oe.stats()["edge_overflow"]
+
+
+def test_leaf_features_are_reference_rows():
+    oe, ge = make_pair(games=16, visits=8, seed=3)
+    for _ in range(5):
+        n_o, need = oe.select()
+        n = ge.select()
+        feats, games = ge.leaf_features(n)
+        assert list(games) == [g for g in range(16) if need[g]]
+        for row, g in zip(feats, games):
+            assert (row == oe.leaf_features(int(g))).all()
+        logits, values = synthetic_evals(oe.leaf_boards())
+        oe.backup(logits, values)
+        ge.set_evals(logits, values)
+        ge.backup()
+
+
+def test_device_resident_selfplay_with_builtin_net():
+    conv, bn = model.random_init(2, 128, seed=2)
+    net = link.Net(conv, bn)
+    ocfg = orc.make_config(64, 24, seed=11, max_plies=400)
+    ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+    lines = []
+    for _ in range(40):
+        ge.run(net, 200, link.DTYPE_BF16)
+        lines += ge.drain_json()
+        if len(lines) >= 40:
+            break
+    st = ge.stats()
+    assert st["games"] == len(lines) >= 40 and st["ring_overflow"] == 0 and st["edge_overflow"] == 0
+    assert st["nn_evals"] > st["plies"] and st["steps"] >= st["nn_evals"] - st["plies"] - 64
+    for line in lines[:20]:
+        entry = json.loads(line)
+        assert entry["result"] in (1, 2)
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+        # root visit counts reach the threshold: each dist is k / N with N >= visits
+        assert all(min(d.values()) > 0 for d in entry["dists"])

@@ -1,0 +1,67 @@
+"""Network parity: the fused HIP tower against the float64 numpy restatement of
+model.py (oracle/net_oracle.py) on identical boards.
+
+Tolerances: f32 MFMA path <= 1e-5 absolute on logits and value (BASELINE.json
+north_star); bf16 / f16 paths are reduced-precision by construction and are bounded
+against the f32 path (5e-2 / 1e-2 absolute on O(1) logits), reported, not claimed."""
+import numpy as np
+import pytest
+
+from ataxxzero_amd import link, model
+from oracle import net_oracle
+from oracle import oracle_lib as orc
+from tests.helpers import BLOCK4_MASK
+
+pytestmark = pytest.mark.gpu
+
+
+def sample_leaf_boards(n, seed, blockers):
+    p = orc.pos_from_fen(orc.START_FEN_PLAIN)
+    plies, results, boards, moves = link.random_play(64, seed, p.pieces[0], p.pieces[1], blockers, 0, 300)
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        g = int(rng.integers(0, 64))
+        ply = int(rng.integers(0, max(plies[g], 1)))
+        x, o = int(boards[g, ply, 0]), int(boards[g, ply, 1])
+        out.append([x, o] if ply % 2 == 0 else [o, x])
+    return np.array(out, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("blocks,n,perturb", [(2, 37, True), (12, 20, False), (8, 7, True)])
+def test_f32_tower_within_1e5_of_float64_restatement(blocks, n, perturb):
+    conv, bn = model.random_init(blocks, 128, seed=10 + blocks, perturb_bn=perturb)
+    lb = sample_leaf_boards(n, 3, BLOCK4_MASK)
+    net = link.Net(conv, bn)
+    logits, values = net.forward(lb, BLOCK4_MASK, link.DTYPE_F32)
+    ref_p, ref_v = net_oracle.forward(conv, bn, net_oracle.features_from_leaf_boards(lb, BLOCK4_MASK))
+    assert np.abs(logits - ref_p).max() <= 1e-5, np.abs(logits - ref_p).max()
+    assert np.abs(values - ref_v).max() <= 1e-5
+    assert np.abs(ref_p).max() > 1e-3  # the comparison is not vacuous
+
+
+def test_first_boards_of_partial_tiles_and_empty_batch():
+    conv, bn = model.random_init(1, 128, seed=4, perturb_bn=True)
+    net = link.Net(conv, bn)
+    lb = sample_leaf_boards(13, 8, 0)
+    full_p, full_v = net.forward(lb, 0, link.DTYPE_F32)
+    for k in (1, 2, 3, 4, 7):
+        p, v = net.forward(lb[:k], 0, link.DTYPE_F32)
+        assert (p == full_p[:k]).all() and (v == full_v[:k]).all()  # batch position does not change a board's result
+    p, v = net.forward(lb[:0], 0, link.DTYPE_F32)
+    assert p.shape == (0, 7, 7, 17)
+
+
+@pytest.mark.parametrize("dtype,tol", [(link.DTYPE_BF16, 5e-2), (link.DTYPE_F16, 1e-2)])
+def test_reduced_precision_tower_tracks_f32(dtype, tol):
+    conv, bn = model.random_init(12, 128, seed=1)
+    lb = sample_leaf_boards(50, 5, BLOCK4_MASK)
+    net = link.Net(conv, bn)
+    p32, v32 = net.forward(lb, BLOCK4_MASK, link.DTYPE_F32)
+    p, v = net.forward(lb, BLOCK4_MASK, dtype)
+    err_p, err_v = np.abs(p - p32).max(), np.abs(v - v32).max()
+    print("dtype %d: max |dlogit| %.3e, max |dvalue| %.3e, logit scale %.3e" % (dtype, err_p, err_v, np.abs(p32).max()))
+    assert err_p <= tol and err_v <= tol
+    # same argmax move on nearly every board
+    same = (p.reshape(len(p), -1).argmax(1) == p32.reshape(len(p), -1).argmax(1)).mean()
+    assert same >= 0.8

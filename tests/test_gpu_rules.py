@@ -1,0 +1,140 @@
+"""GPU rules parity: movegen / makemove / adjudication / perft / features, bit-exact
+against the golden vectors (from the reference's Python rules) and the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ataxxzero_amd import link
+from oracle import oracle_lib as orc
+from tests.helpers import BLOCK4_MASK, GOLDEN, fixture_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def test_perft_matches_reference_tables():
+    with open(os.path.join(GOLDEN, "perft.json")) as f:
+        table = json.load(f)
+    for key, blockers in (("noblock", 0), ("block4", BLOCK4_MASK)):
+        p = orc.pos_from_fen(table[key]["fen"])
+        for d, n in table[key]["depth"].items():
+            assert link.perft(p.pieces[0], p.pieces[1], blockers, p.turn, int(d)) == n, (key, d)
+    # depths the reference's C++ rules were measured at in SURVEY.md §0
+    p = orc.pos_from_fen(orc.START_FEN_PLAIN)
+    assert link.perft(p.pieces[0], p.pieces[1], 0, 0, 6) == 141870600
+    assert link.perft(p.pieces[0], p.pieces[1], BLOCK4_MASK, 0, 5) == 3639872
+    assert link.perft(p.pieces[0], p.pieces[1], BLOCK4_MASK, 0, 6) == 97541128
+    q = orc.pos_from_fen("x5o/7/2-1-2/7/2-1-2/7/o5x x")
+    assert link.perft(q.pieces[0], q.pieces[1], q.blockers, 0, 5) == 2266352
+
+
+def test_perft_split_matches_reference():
+    with open(os.path.join(GOLDEN, "perft.json")) as f:
+        table = json.load(f)
+    t = table["noblock"]
+    for mv, n in t["split_d4"].items():
+        p = orc.pos_from_fen(t["fen"])
+        c = orc.move_from_string(mv)
+        orc.lib().orc_makemove(p, c & 0xFF, c >> 8)
+        assert link.perft(p.pieces[0], p.pieces[1], 0, p.turn, 3) == n
+
+
+def test_wave_movegen_and_result_match_fixtures_and_oracle():
+    for blockers in (0, BLOCK4_MASK):
+        items = [it for it in fixture_positions() if it[1] == blockers]
+        boards = np.stack([it[0] for it in items])
+        moves, counts, results = link.rules_batch(boards, blockers)
+        for i, (packed, _, rec) in enumerate(items):
+            p = orc.pos_from_fen(rec["fen"])
+            p.blockers = blockers
+            want = orc.movegen(p)
+            res = orc.result(p)
+            assert results[i] == res == rec["result"]
+            if orc.lib().orc_result(p, None, None) and (p.pieces[0] == 0 or p.pieces[1] == 0):
+                assert counts[i] == 0  # adjudicated before movegen (cpp/self_play_client.cpp:119-122)
+                continue
+            assert counts[i] == len(want)
+            assert (moves[i, :counts[i]] == want).all(), rec["fen"]  # exact reference order
+            got = sorted(orc.move_string(m) for m in moves[i, :counts[i]]) or ["0000"]
+            assert got == rec["moves"]
+
+
+def test_makemove_matches_fixtures():
+    for blockers in (0, BLOCK4_MASK):
+        boards, mvs, want = [], [], []
+        for packed, bl, rec in fixture_positions():
+            if bl != blockers:
+                continue
+            for mv, fen2 in rec["succ"].items():
+                boards.append(packed)
+                mvs.append(0xFFFF if mv == "0000" else orc.move_from_string(mv))
+                want.append(fen2)
+        out = link.makemove_batch(np.stack(boards), np.array(mvs, dtype=np.uint16))
+        for row, fen2 in zip(out, want):
+            q = orc.Pos()
+            q.pieces[0], q.pieces[1] = int(row[0]) & ~(1 << 63), int(row[1])
+            q.turn = int(row[0]) >> 63
+            assert orc.fen(q) == fen2
+
+
+def test_features_match_oracle():
+    items = fixture_positions(limit=400)
+    for blockers in (0, BLOCK4_MASK):
+        sel = [it for it in items if it[1] == blockers]
+        leaf = []
+        for packed, _, rec in sel:
+            p = orc.pos_from_fen(rec["fen"])
+            leaf.append([p.pieces[p.turn], p.pieces[1 - p.turn]])
+        got = link.features_batch(np.array(leaf, dtype=np.uint64), blockers)
+        for i, (packed, _, rec) in enumerate(sel):
+            p = orc.pos_from_fen(rec["fen"])
+            p.blockers = blockers
+            assert (got[i] == orc.features(p)).all()
+
+
+def test_random_play_games_are_legal():
+    p = orc.pos_from_fen(orc.START_FEN_PLAIN)
+    plies, results, boards, moves = link.random_play(256, 99, p.pieces[0], p.pieces[1], 0, 0, 400)
+    assert (results > 0).sum() >= 250 and plies.min() >= 4
+    assert 120 < plies.mean() < 240  # reference random play: mean 182 plies
+    for g in range(0, 256, 8):
+        q = orc.pos_from_fen(orc.START_FEN_PLAIN)
+        for ply in range(plies[g]):
+            assert int(boards[g, ply, 0]) == q.pieces[0] and int(boards[g, ply, 1]) == q.pieces[1]
+            assert orc.result(q) == 0
+            mv = int(moves[g, ply])
+            assert mv in set(int(m) for m in orc.movegen(q))
+            orc.lib().orc_makemove(q, mv & 0xFF, mv >> 8)
+        assert orc.result(q) == results[g]
+
+
+def test_detmath_bits_match_oracle():
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-90, 89, 4000), [-87.0, 88.0, 0.0, -0.0, 1e-8, -100.0, 100.0]]).astype(np.float32)
+    got = link.probe_detmath(0, xs)
+    want = np.array([np.float32(orc.lib().orc_probe_expf(float(x))) for x in xs], dtype=np.float32).view(np.uint32)
+    assert (got == want).all()
+    assert np.allclose(got.view(np.float32)[:4000], np.exp(xs[:4000].astype(np.float64)), rtol=1e-6, atol=1e-37)
+    ys = np.concatenate([np.exp(rng.uniform(-80, 80, 4000)), [1.0, 0.5, 2.0, 1e-30]]).astype(np.float32)
+    got = link.probe_detmath(1, ys)
+    want = np.array([np.float32(orc.lib().orc_probe_logf(float(y))) for y in ys], dtype=np.float32).view(np.uint32)
+    assert (got == want).all()
+    assert np.allclose(got.view(np.float32), np.log(ys.astype(np.float64)), rtol=2e-6, atol=2e-7)
+    aux = rng.integers(0, 2**32, size=(500, 4), dtype=np.uint64).astype(np.uint32)
+    got = link.probe_detmath(3, aux=aux.ravel(), seed=0x123456789ABCDEF).reshape(500, 4)
+    out = np.zeros(4, dtype=np.uint32)
+    for i in range(500):
+        orc.lib().orc_probe_philox(0x123456789ABCDEF, int(aux[i, 0]), int(aux[i, 1]), int(aux[i, 2]), int(aux[i, 3]),
+                                   out.ctypes.data)
+        assert (got[i] == out).all()
+    # Philox4x32-10 known answer (Random123 kat_vectors: counter 0, key 0)
+    z = link.probe_detmath(3, aux=np.zeros(4, dtype=np.uint32), seed=0)
+    assert [hex(v) for v in z] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    aux3 = np.stack([rng.integers(0, 5000, 3000), rng.integers(0, 400, 3000), rng.integers(0, 256, 3000)], axis=1).astype(np.uint32)
+    got = link.probe_detmath(2, values=np.array([0.15], dtype=np.float32), aux=aux3.ravel(), seed=20260101)
+    want = np.array([np.float32(orc.lib().orc_probe_gamma(0.15, 20260101, int(a), int(b), int(c))) for a, b, c in aux3],
+                    dtype=np.float32).view(np.uint32)
+    assert (got == want).all()
+    g = got.view(np.float32).astype(np.float64)
+    assert abs(g.mean() - 0.15) < 0.03 and abs(g.var() - 0.15) < 0.06  # Gamma(0.15, 1): mean = var = 0.15
