@@ -1,0 +1,70 @@
+"""The C-ABI library loads on a GPU-less box and exports every symbol the public header
+declares; compute entry points fail loudly (no CPU fallback) when no device is visible."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ataxxzero_amd import link
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ataxxzero_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_]\w*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(n for n in names if n.startswith("azh_") or n in
+                      ("launch_threads", "get_workload", "complete_workload", "shutdown")))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    dll = link.load()
+    names = declared_symbols()
+    assert len(names) >= 30 and "launch_threads" in names and "azh_engine_run" in names
+    for name in names:
+        assert hasattr(dll, name), name
+        assert name in link.SIGNATURES, "link.py does not bind %s" % name
+    assert sorted(link.SIGNATURES) == names  # and binds nothing the header does not declare
+
+
+def test_reference_abi_argument_order_matches_link_py():
+    # link.py:8-32: launch_threads(char*, int, float*, float*, int, int); get_workload() -> int;
+    # complete_workload(int, float*, float*) (cpp/self_play_client.cpp:723); shutdown()
+    sig = link.SIGNATURES
+    assert sig["launch_threads"][1] == [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_int]
+    assert sig["get_workload"] == (ctypes.c_int, [])
+    assert sig["complete_workload"][1] == [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert sig["shutdown"] == (None, [])
+
+
+@pytest.mark.skipif(link.device_count() > 0, reason="checks the no-GPU failure mode")
+def test_compute_calls_fail_loudly_without_a_gpu():
+    with pytest.raises(link.AzhError):
+        link.perft(1, 2, 0, 0, 2)
+    with pytest.raises(link.AzhError):
+        link.rules_batch(np.zeros((1, 2), dtype=np.uint64), 0)
+    cfg = link.Config(games=4, visits=8, max_plies=10, edges_per_node=16, c_puct=1.0, dirichlet_alpha=0.15,
+                      dirichlet_weight=0.25, start_turn=0, seed=1, start_x=1, start_o=2, blockers=0)
+    with pytest.raises(link.AzhError) as ei:
+        link.Engine(cfg)
+    assert "no CPU fallback" in str(ei.value) or "device" in str(ei.value)
+    with pytest.raises(link.AzhError):
+        link.require_gpu()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ataxxzero_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".cuh")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert not re.search(r'#include\s+"[^"]*oracle', text), f  # comments may cite it; code may not include it
+    for f in ("accelerated_generate_games.py", "generate_games.py"):
+        path = os.path.join(ROOT, f)
+        if os.path.exists(path):
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", open(path).read(), flags=re.M), f

@@ -1,0 +1,96 @@
+"""Oracle search engine: invariants the reference's algorithm implies (the oracle is the
+checker for the HIP engine, so it is itself checked against the reference's semantics)."""
+import numpy as np
+
+from oracle import oracle_lib as orc
+from tests.helpers import replay_game_entry, synthetic_evals
+
+
+def run(e, iters, evaluator):
+    games = []
+    for _ in range(iters):
+        e.select()
+        logits, values = evaluator(e.leaf_boards())
+        e.backup(logits, values)
+        games += e.pop_games()
+    return games
+
+
+def null_eval(lb):
+    return np.zeros((len(lb), 833), np.float32), np.zeros(len(lb), np.float32)
+
+
+def test_philox_known_answers_and_detmath_accuracy():
+    out = np.zeros(4, np.uint32)
+    orc.lib().orc_probe_philox(0, 0, 0, 0, 0, out.ctypes.data)
+    assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    orc.lib().orc_probe_philox(0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, out.ctypes.data)
+    assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    xs = np.random.default_rng(0).uniform(-80, 80, 500).astype(np.float32)
+    e = np.array([orc.lib().orc_probe_expf(float(x)) for x in xs])
+    assert np.allclose(e, np.exp(xs.astype(np.float64)), rtol=3e-7)
+    g = np.array([orc.lib().orc_probe_gamma(0.15, 1, i, 0, 0) for i in range(20000)])
+    assert abs(g.mean() - 0.15) < 0.01 and abs(g.var() - 0.15) < 0.02  # Gamma(0.15,1)
+
+
+def test_games_replay_and_root_visits_reach_threshold():
+    e = orc.Engine(orc.make_config(games=12, visits=20, seed=3))
+    games = run(e, 2500, synthetic_evals)
+    assert len(games) >= 6
+    st = e.stats()
+    assert st["games"] == len(games) and st["edge_overflow"] == 0
+    # NN evals per ply = steps that reached a new non-terminal node + 1 root refresh (:489-490)
+    assert st["nn_evals"] <= st["steps"] + st["plies"] + 12
+    for rec in games:
+        entry = rec["entry"]
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"] and entry["result"] in (1, 2)
+        assert all(abs(sum(d.values()) - 1) < 1e-12 for d in entry["dists"])
+
+
+def test_tree_invariants_during_search():
+    e = orc.Engine(orc.make_config(games=4, visits=50, seed=8))
+    for it in range(260):
+        e.select()
+        logits, values = synthetic_evals(e.leaf_boards())
+        e.backup(logits, values)
+        if it % 20 != 19:
+            continue
+        for g in range(4):
+            s = e.game_state(g)
+            boards, info, edges, moves = e.tree(g)
+            assert s.n_nodes <= e.node_cap and s.n_nodes <= 50 + 2  # nodes <= visits + 1
+            first, m = info[0, 0], info[0, 1] & 0xFFFF
+            root_edges = edges[first:first + m]
+            assert int(root_edges[:, 1].sum()) == s.root_visits  # all_edge_visits == sum of edge visits
+            if s.phase == 1:
+                pri = root_edges[:, 0].copy().view(np.float32)
+                assert abs(float(pri.sum()) - 1.0) < 1e-4  # priors renormalised over legal moves (:241-245)
+            # every child pointer is a valid node and each node has one parent
+            kids = edges[:, 3][edges[:, 3] != 0xFFFFFFFF]
+            assert len(set(kids.tolist())) == len(kids) == s.n_nodes - 1
+            # W / n in [0, 1]: scores are probabilities of winning (:447)
+            n = edges[:, 1].astype(np.float64)
+            w = edges[:, 2].copy().view(np.float32).astype(np.float64)
+            assert ((w >= -1e-6) & (w <= n + 1e-4)).all()
+
+
+def test_dirichlet_noise_only_at_root_and_null_net_uniform_priors():
+    e = orc.Engine(orc.make_config(games=2, visits=30, seed=1, weight=0.0))
+    e.select()
+    e.backup(*null_eval(e.leaf_boards()))
+    boards, info, edges, moves = e.tree(0)
+    m = info[0, 1] & 0xFFFF
+    pri = edges[:m, 0].copy().view(np.float32)
+    assert np.allclose(pri, 1.0 / m, rtol=1e-6)  # zero logits -> uniform over legal moves
+    e2 = orc.Engine(orc.make_config(games=2, visits=30, seed=1, weight=0.25))
+    e2.select()
+    e2.backup(*null_eval(e2.leaf_boards()))
+    pri2 = e2.tree(0)[2][:m, 0].copy().view(np.float32)
+    assert abs(pri2.sum() - 1) < 1e-5 and pri2.std() > 1e-3 and (pri2 >= 0.75 / m - 1e-6).all()
+
+
+def test_plies_cap_drops_games():
+    e = orc.Engine(orc.make_config(games=6, visits=4, seed=2, max_plies=10))
+    games = run(e, 400, synthetic_evals)
+    st = e.stats()
+    assert st["dropped"] > 0 and all(len(r["entry"]["moves"]) <= 10 for r in games)
