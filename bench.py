@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched MCTS self-play on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step is one search iteration of the hot path over one batch: every one of the
+`games` concurrent trees descends by PUCT, expands one leaf, the fused conv tower
+evaluates the leaf batch, and the results are backed up (plus move sampling / re-rooting /
+game turnover for the trees whose root reached `visits`).  Metric (BASELINE.json):
+MCTS node-evals/s at 400 sims/move; games/s reported beside it.  Workload at N=1: 4096
+concurrent games, 400 sims/move, 12x128 net (random-init seed 1, .npy layout), bf16 — the
+per-GPU shard of BASELINE.json configs[2] (32768 games over 8 GPUs), i.e. configs[1]'s game
+count at the sims/move the metric is quoted on.  N ranks = N x 4096 games, weak scaling, no
+data-path collective.
+
+Prints ONE JSON line on rank 0, with the dominant kernel's roofline (MFMA, measured with
+HIP events on the engine's stream) and a CPU baseline (the oracle port on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def tree_bytes(d, logit_bytes=4):
+    """Algorithmic bytes of the tree kernels: per step 16L + 12C (select) +
+    24L (backup) + 32 + 18M (expand) + 834e (policy row + value)."""
+    return (40 * d["levels"] + 12 * d["children"] + 32 * d["steps"] + 18 * d["new_moves"] +
+            834 * logit_bytes * d["nn_evals"])
+
+
+def cpu_baseline(conv, bn, visits, seconds=15.0, games=128):
+    """The oracle port (sequential PUCT per game + numpy f32 net) on the host cores, on a
+    bounded sample of the same workload: `games` concurrent games at the same sims/move."""
+    import numpy as np
+    from oracle import net_oracle
+    from oracle import oracle_lib as orc
+    cfg = orc.make_config(games=games, visits=visits, seed=20260101)
+    eng = orc.Engine(cfg)
+    logits = np.zeros((games, 833), np.float32)
+    values = np.zeros(games, np.float32)
+    t0 = time.time()
+    iters = 0
+    while time.time() - t0 < seconds:
+        n, need = eng.select()
+        lb = eng.leaf_boards()
+        idx = np.nonzero(need)[0]
+        if len(idx):
+            p, v = net_oracle.forward(conv, bn, net_oracle.features_from_leaf_boards(lb[idx], cfg.blockers, np.float32),
+                                      dtype=np.float32)
+            logits[idx] = p.reshape(len(idx), 833)
+            values[idx] = v.reshape(len(idx))
+        eng.backup(logits, values)
+        iters += 1
+    dt = time.time() - t0
+    st = eng.stats()
+    return {"value": st["steps"] / dt, "unit": "node-evals/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d concurrent games x %d iterations (%.1f s): oracle tree search (1 thread) + numpy f32 "
+                      "conv tower (BLAS threads = host cores), same net / sims-per-move" % (games, iters, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--visits", type=int, default=400)
+    ap.add_argument("--blocks", type=int, default=12)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--chunk", type=int, default=250, help="iterations between finished-game drains")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    from ataxxzero_amd import distrib, link, model, selfplay
+    group = distrib.Group()
+    if group.world != args.gpus and group.world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, group.world))
+    link.require_gpu()
+    link.check(link.load().azh_set_device(group.local_rank))
+
+    conv, bn = model.random_init(args.blocks, 128, seed=1)
+    sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
+                           seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank))
+    eng = sp.engine
+
+    def run(iters):
+        done = 0
+        finished = 0
+        while done < iters:
+            n = min(args.chunk, iters - done)
+            sp.run(n)
+            finished += len(sp.drain())   # sync + hand finished games to the host, as the CLI does
+            done += n
+        return finished
+
+    run(args.warmup)
+    eng.sync()
+    group.barrier()
+    st0 = eng.stats()
+    eng.timing_reset(True)
+    t0 = time.perf_counter()
+    finished = run(args.steps)
+    eng.sync()
+    t1 = time.perf_counter()
+    group.barrier()
+    st1 = eng.stats()
+    tm = eng.timing()
+    d = {k: st1[k] - st0[k] for k in st1}
+    steps_total, t_max, rate = distrib.aggregate(group, d["steps"], t1 - t0)
+    evals_total = group.reduce(d["nn_evals"], "sum")
+    plies_total = group.reduce(d["plies"], "sum")
+    games_total = group.reduce(finished, "sum")
+
+    if group.rank == 0:
+        flops = model.flops_per_eval(args.blocks, 128)
+        it = max(tm["iterations"], 1)
+        frac_timed = it / float(args.steps)
+        net_s = tm["net_ms"] * 1e-3
+        achieved_tf = d["nn_evals"] * frac_timed * flops / net_s / 1e12 if net_s > 0 else 0.0
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        tree_s = (tm["select_ms"] + tm["backup_ms"]) * 1e-3
+        tree_gbs = tree_bytes(d) * frac_timed / tree_s / 1e9 if tree_s > 0 else 0.0
+        out = {
+            "metric": "MCTS node-evals/s at %d sims/move (self-play; games/s beside it)" % args.visits,
+            "value": rate, "unit": "node-evals/s", "n_gpus": group.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init .npy-layout weights, seed 1; "
+                                                              "self-play from the reference start position)",
+            "config": {"workload": "%d concurrent self-play games per GPU, %d sims/move, %dx128 conv net, %s "
+                                   "(per-GPU shard of BASELINE configs[2]; configs[1] at the metric's 400 sims)"
+                                   % (args.games, args.visits, args.blocks, args.dtype),
+                       "games_per_gpu": args.games, "visits": args.visits, "net": "%dx128" % args.blocks,
+                       "parallelism": "%d independent game shards, no collective" % group.world},
+            "nn_evals_per_s": evals_total / t_max, "plies_per_s": plies_total / t_max,
+            "games_per_s": games_total / t_max,
+            "games_per_s_steady_state_est": (plies_total / t_max) / 182.4 if plies_total else None,
+            "roofline": {"bound": "mfma", "kernel": "k_tower<%s>" % args.dtype, "achieved": achieved_tf, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": None,
+                         "avg_launch_ms": tm["net_ms"] / it, "evals_per_launch": d["nn_evals"] / float(args.steps),
+                         "flops_per_eval": flops},
+            "tree_roofline": {"bound": "hbm", "kernels": "k_select+k_compact / k_backup+k_advance",
+                              "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS,
+                              "select_ms_per_step": tm["select_ms"] / it, "backup_ms_per_step": tm["backup_ms"] / it,
+                              "bytes_per_step": tree_bytes(d) / float(max(d["steps"], 1)),
+                              "levels_per_step": d["levels"] / float(max(d["steps"], 1)),
+                              "children_per_step": d["children"] / float(max(d["steps"], 1))},
+            "counters": d,
+        }
+        if group.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(conv, bn, args.visits, seconds=args.cpu_seconds)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    sp.close()
+    group.close()
+
+
+if __name__ == "__main__":
+    main()
