@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "azh_host.h"
 
@@ -53,7 +54,6 @@ template <> struct Traits<AZH_DTYPE_BF16> {
     typedef bf16x8 afrag;     // 8 consecutive k of one output channel
     typedef bf16x4 quad;
     static constexpr int KSTEP = 16;   // k per MFMA
-    static constexpr int BOARDS = 6;
     static constexpr int ESIZE = 2;
     __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
@@ -62,7 +62,6 @@ template <> struct Traits<AZH_DTYPE_F16> {
     typedef f16x8 afrag;
     typedef f16x4 quad;
     static constexpr int KSTEP = 16;
-    static constexpr int BOARDS = 6;
     static constexpr int ESIZE = 2;
     __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
@@ -71,14 +70,16 @@ template <> struct Traits<AZH_DTYPE_F32> {
     typedef float afrag;      // one k of one output channel
     typedef f32x4 quad;
     static constexpr int KSTEP = 2;
-    static constexpr int BOARDS = 3;
     static constexpr int ESIZE = 4;
     __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 };
 
-template <int DT> struct Geo {
+// BOARDS boards per workgroup.  16-bit types: 6 boards fill one CU's LDS (one workgroup per
+// CU, one wave per SIMD); 3 boards let two workgroups share a CU (two waves per SIMD hide
+// each other's LDS / L2 latency and smooth the tail of the grid).  f32: 3 boards.
+template <int DT, int NB> struct Geo {
     typedef Traits<DT> Tr;
-    static constexpr int BOARDS = Tr::BOARDS;
+    static constexpr int BOARDS = NB;
     static constexpr int NC = 49 * BOARDS;             // real cells per workgroup
     static constexpr int NT = (NC + 31) / 32;          // 32-cell MFMA column tiles
     static constexpr int ROWB = F * Tr::ESIZE;         // bytes per cell row
@@ -93,9 +94,9 @@ template <int DT> struct Geo {
 template <int DT> __device__ inline int unit_off(int row, int u)
 {
     if constexpr (DT == AZH_DTYPE_F32)
-        return row * Geo<DT>::ROWB + ((u ^ (row & 31)) << 2);
+        return row * (F * 4) + ((u ^ (row & 31)) << 2);
     else
-        return row * Geo<DT>::ROWB + ((u ^ (row & 15)) << 4);
+        return row * (F * 2) + ((u ^ (row & 15)) << 4);
 }
 
 struct TowerArgs {
@@ -115,48 +116,79 @@ struct TowerArgs {
     float *values;           // [..], indexed by game
 };
 
-template <int DT>
+template <int DT, int NB>
 __device__ inline void conv_layer(const unsigned char *in, unsigned char *out, const unsigned char *skip,
                                   const typename Traits<DT>::afrag *__restrict__ wp, int ksteps,
                                   const float *__restrict__ scale, const float *__restrict__ shift,
-                                  const int (&vmask)[Geo<DT>::NT], int wave, int lane)
+                                  const int (&vmask)[Geo<DT, NB>::NT], int wave, int lane)
 {
     typedef Traits<DT> Tr;
-    typedef Geo<DT> G;
+    typedef Geo<DT, NB> G;
     typedef typename Tr::afrag afrag;
+    constexpr int NT = G::NT;
+    constexpr int USHIFT = DT == AZH_DTYPE_F32 ? 2 : 4;
+    constexpr int UMASK = DT == AZH_DTYPE_F32 ? 31 : 15;
     const int r = lane & 31, h = lane >> 5;
-    f32x16 acc[G::NT];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int ct = 0; ct < G::NT; ct++)
+    for (int ct = 0; ct < NT; ct++)
 #pragma unroll
         for (int i = 0; i < 16; i++)
             acc[ct][i] = 0.0f;
 
     // A fragments of this wave: index ((tap*ksteps + ks)*OCT + wave)*64 + lane
     const afrag *wq = wp + wave * 64 + lane;
+    constexpr size_t S = OCT * 64;
     const int total = 9 * ksteps;
-    afrag a0 = wq[0];
-    afrag a1 = wq[(total > 1 ? 1 : 0) * (OCT * 64)];
-    int step = 0;
-    for (int tap = 0; tap < 9; tap++) {
+
+    // B-fragment addressing of the current tap: byte offset of the source row and its swizzle key
+    int rowoff[NT], rsw[NT];
+    auto set_rows = [&](int tap) {
         const int drow = (tap / 3 - 1) * 7 + (tap % 3 - 1);
-        int rows[G::NT];
 #pragma unroll
-        for (int ct = 0; ct < G::NT; ct++)
-            rows[ct] = ((vmask[ct] >> tap) & 1) ? (ct * 32 + r + drow) : G::NC;
-        for (int ks = 0; ks < ksteps; ks++, step++) {
-            const int nxt = step + 2 < total ? step + 2 : total - 1;
-            afrag a2 = wq[(size_t)nxt * (OCT * 64)];
-            const int u = (DT == AZH_DTYPE_F32) ? (2 * ks + h) : (2 * ks + h);
-#pragma unroll
-            for (int ct = 0; ct < G::NT; ct++) {
-                const afrag b = *reinterpret_cast<const afrag *>(in + unit_off<DT>(rows[ct], u));
-                acc[ct] = Tr::mfma(a0, b, acc[ct]);
-            }
-            a0 = a1;
-            a1 = a2;
+        for (int ct = 0; ct < NT; ct++) {
+            const int row = ((vmask[ct] >> tap) & 1) ? (ct * 32 + r + drow) : G::NC;
+            rowoff[ct] = row * G::ROWB;
+            rsw[ct] = row & UMASK;
         }
+    };
+    auto load_b = [&](afrag (&bf)[NT], int ks) {
+        const int u = 2 * ks + h;
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++)
+            bf[ct] = *reinterpret_cast<const afrag *>(in + rowoff[ct] + ((u ^ rsw[ct]) << USHIFT));
+    };
+
+    // Software pipeline: while the MFMAs of step s run, the B fragments of step s+1 are
+    // already on their way from LDS and the A fragment of step s+2 from L2.
+    afrag b0[NT], b1[NT];
+    int tap = 0, ks = 0;
+    set_rows(0);
+    load_b(b0, 0);
+    afrag a0 = wq[0];
+    afrag a1 = wq[(size_t)(total > 1 ? 1 : 0) * S];
+    auto step = [&](afrag (&cur)[NT], afrag (&nxt)[NT], int s) {
+        if (s + 1 < total) {
+            if (++ks == ksteps) {
+                ks = 0;
+                set_rows(++tap);
+            }
+            load_b(nxt, ks);
+        }
+        const afrag a2 = wq[(size_t)(s + 2 < total ? s + 2 : total - 1) * S];
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++)
+            acc[ct] = Tr::mfma(a0, cur[ct], acc[ct]);
+        a0 = a1;
+        a1 = a2;
+    };
+    int s = 0;
+    for (; s + 1 < total; s += 2) {
+        step(b0, b1, s);
+        step(b1, b0, s + 1);
     }
+    if (s < total)
+        step(b0, b1, s);
 
     // epilogue: bn, (+skip), relu, convert, write [cell][channel]
     float sc[16], sh[16];
@@ -210,11 +242,11 @@ __device__ inline void conv_layer(const unsigned char *in, unsigned char *out, c
     }
 }
 
-template <int DT>
-__global__ __launch_bounds__(NTHREADS, 1) void k_tower(TowerArgs A)
+template <int DT, int NB, int WPS>
+__global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
 {
     typedef Traits<DT> Tr;
-    typedef Geo<DT> G;
+    typedef Geo<DT, NB> G;
     typedef typename Tr::afrag afrag;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,15 +315,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_tower(TowerArgs A)
     const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w);
     const size_t l0 = (size_t)9 * G::KSTEPS_IN * OCT * 64;
     const size_t lf = (size_t)9 * G::KSTEPS_FULL * OCT * 64;
-    conv_layer<DT>(buf0, buf1, nullptr, wp, G::KSTEPS_IN, A.scale, A.shift, vmask, wave, lane);
+    conv_layer<DT, NB>(buf0, buf1, nullptr, wp, G::KSTEPS_IN, A.scale, A.shift, vmask, wave, lane);
     __syncthreads();
     wp += l0;
     for (int b = 0; b < A.blocks; b++) {
         const float *s1 = A.scale + (size_t)(1 + 2 * b) * F, *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer<DT>(buf1, buf0, nullptr, wp, G::KSTEPS_FULL, s1, t1, vmask, wave, lane);
+        conv_layer<DT, NB>(buf1, buf0, nullptr, wp, G::KSTEPS_FULL, s1, t1, vmask, wave, lane);
         __syncthreads();
         wp += lf;
-        conv_layer<DT>(buf0, buf1, buf1, wp, G::KSTEPS_FULL, s1 + F, t1 + F, vmask, wave, lane);
+        conv_layer<DT, NB>(buf0, buf1, buf1, wp, G::KSTEPS_FULL, s1 + F, t1 + F, vmask, wave, lane);
         __syncthreads();
         wp += lf;
     }
@@ -498,20 +530,33 @@ extern "C" void azh_net_destroy(azh_net *net)
     delete net;
 }
 
-template <int DT> static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
+template <int DT, int NB, int WPS> static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
 {
-    typedef Geo<DT> G;
+    typedef Geo<DT, NB> G;
     static bool attr_set = false;
     if (!attr_set) {
-        AZH_HIP(hipFuncSetAttribute((const void *)k_tower<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        AZH_HIP(hipFuncSetAttribute((const void *)k_tower<DT, NB, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    G::LDS_BYTES));
         attr_set = true;
     }
     const int grid = (max_n + G::BOARDS - 1) / G::BOARDS;
     if (grid <= 0)
         return 0;
-    hipLaunchKernelGGL(k_tower<DT>, dim3(grid), dim3(NTHREADS), G::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL((k_tower<DT, NB, WPS>), dim3(grid), dim3(NTHREADS), G::LDS_BYTES, stream, args);
     AZH_HIP(hipGetLastError());
     return 0;
+}
+
+// Boards per workgroup for the 16-bit towers: 3 (two workgroups per CU) unless
+// AZH_TOWER_BOARDS=6 asks for one 6-board workgroup per CU.
+static int tower_boards()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("AZH_TOWER_BOARDS");
+        v = (e && atoi(e) == 6) ? 6 : 3;
+    }
+    return v;
 }
 
 // Evaluate up to max_n boards (dense list `list`/`count` on the device, or the
@@ -539,10 +584,13 @@ int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, 
     a.blockers = blockers;
     a.logits = d_logits;
     a.values = d_values;
+    const bool six = tower_boards() == 6;
     switch (dtype) {
-    case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32>(a, max_n, stream);
-    case AZH_DTYPE_BF16: return launch_tower<AZH_DTYPE_BF16>(a, max_n, stream);
-    default: return launch_tower<AZH_DTYPE_F16>(a, max_n, stream);
+    case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 3, 1>(a, max_n, stream);
+    case AZH_DTYPE_BF16:
+        return six ? launch_tower<AZH_DTYPE_BF16, 6, 1>(a, max_n, stream) : launch_tower<AZH_DTYPE_BF16, 3, 2>(a, max_n, stream);
+    default:
+        return six ? launch_tower<AZH_DTYPE_F16, 6, 1>(a, max_n, stream) : launch_tower<AZH_DTYPE_F16, 3, 2>(a, max_n, stream);
     }
 }
 
@@ -565,6 +613,52 @@ extern "C" int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *l
         AZH_HIP(hipMemcpy(logits_out, d_l, (size_t)n * 833 * 4, hipMemcpyDeviceToHost));
         AZH_HIP(hipMemcpy(values_out, d_v, (size_t)n * 4, hipMemcpyDeviceToHost));
     }
+    (void)hipFree(d_b);
+    (void)hipFree(d_l);
+    (void)hipFree(d_v);
+    return rc;
+}
+
+// Net-only timing hook: `iters` launches of the tower over n synthetic boards, HIP-event
+// timed on one stream; *ms_out = average milliseconds per launch.
+extern "C" int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out)
+{
+    if (!net || n <= 0 || iters <= 0 || !ms_out)
+        return azh_fail(-1, "azh_net_bench: bad argument");
+    std::vector<unsigned long long> boards((size_t)n * 2);
+    unsigned long long x = 0x9E3779B97F4A7C15ULL;
+    for (int i = 0; i < n; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const unsigned long long m = x & 0x1FFFFFFFFFFFFULL;
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        boards[2 * (size_t)i] = m;
+        boards[2 * (size_t)i + 1] = x & 0x1FFFFFFFFFFFFULL & ~m;
+    }
+    unsigned long long *d_b = nullptr;
+    float *d_l = nullptr, *d_v = nullptr;
+    AZH_HIP(hipMalloc((void **)&d_b, (size_t)n * 16));
+    AZH_HIP(hipMalloc((void **)&d_l, (size_t)n * 833 * 4));
+    AZH_HIP(hipMalloc((void **)&d_v, (size_t)n * 4));
+    AZH_HIP(hipMemcpy(d_b, boards.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    hipStream_t st;
+    hipEvent_t e0, e1;
+    AZH_HIP(hipStreamCreate(&st));
+    AZH_HIP(hipEventCreate(&e0));
+    AZH_HIP(hipEventCreate(&e1));
+    int rc = 0;
+    for (int i = 0; i < 3 && rc == 0; i++)
+        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st);
+    AZH_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters && rc == 0; i++)
+        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st);
+    AZH_HIP(hipEventRecord(e1, st));
+    AZH_HIP(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    AZH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / (float)iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(st);
     (void)hipFree(d_b);
     (void)hipFree(d_l);
     (void)hipFree(d_v);

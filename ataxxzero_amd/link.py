@@ -70,6 +70,7 @@ SIGNATURES = {
     "azh_net_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _f32, _P(_vp)]),
     "azh_net_destroy": (None, [_vp]),
     "azh_net_forward": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
+    "azh_net_bench": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P(_f32)]),
     "azh_engine_create": (ctypes.c_int, [_P(Config), _P(_vp)]),
     "azh_engine_destroy": (None, [_vp]),
     "azh_engine_node_cap": (ctypes.c_int, [_vp]),
@@ -207,7 +208,7 @@ def random_play(n_games, seed, x, o, blockers, turn, max_plies=400, trace=True):
 def probe_detmath(kind, values=None, aux=None, seed=0):
     values = None if values is None else np.ascontiguousarray(values, dtype=np.float32)
     aux = None if aux is None else np.ascontiguousarray(aux, dtype=np.uint32)
-    n = len(values) if kind in (0, 1) else len(aux)
+    n = len(values) if kind in (0, 1) else len(aux) // (3 if kind == 2 else 4)
     out = np.zeros(4 * n if kind == 3 else n, dtype=np.uint32)
     check(load().azh_probe_detmath(kind, n, _ptr(values), _ptr(aux), int(seed), _ptr(out)))
     return out
@@ -237,6 +238,12 @@ class Net:
         values = np.zeros((n, 1), dtype=np.float32)
         check(load().azh_net_forward(self.h, dtype, n, _ptr(leaf_boards), int(blockers), _ptr(logits), _ptr(values)))
         return logits, values
+
+    def bench(self, n, iters=20, dtype=DTYPE_BF16):
+        """Average milliseconds per tower launch over n synthetic boards."""
+        ms = ctypes.c_float(0)
+        check(load().azh_net_bench(self.h, dtype, n, iters, ctypes.byref(ms)))
+        return float(ms.value)
 
     def close(self):
         if getattr(self, "h", None):

@@ -62,7 +62,7 @@ def cpu_baseline(conv, bn, visits, seconds=15.0, games=128):
         iters += 1
     dt = time.time() - t0
     st = eng.stats()
-    return {"value": st["steps"] / dt, "unit": "node-evals/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": st["steps"] / dt, "unit": "node-evals/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
             "sample": "%d concurrent games x %d iterations (%.1f s): oracle tree search (1 thread) + numpy f32 "
                       "conv tower (BLAS threads = host cores), same net / sims-per-move" % (games, iters, dt)}
 

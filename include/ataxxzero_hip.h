@@ -100,6 +100,10 @@ void azh_net_destroy(azh_net *net);
 int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards, uint64_t blockers,
                     float *logits_out, float *values_out);
 
+/* Measurement hook: average HIP-event milliseconds per launch of the tower kernel over
+ * n synthetic boards (iters launches on one stream, 3 untimed warm-up launches). */
+int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out);
+
 /* ------------------------------------------------------------------ engine
  * Replaces the worker threads of cpp/self_play_client.cpp: MCTS::step (:419-473),
  * Evaluations::populate (:153-272), MCTS::play (:475-492),
