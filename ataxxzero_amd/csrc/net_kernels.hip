@@ -42,6 +42,9 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 constexpr int F = 128;        // filters (model.py:16)
 constexpr int OCT = F / 32;   // 32-channel output tiles = waves per workgroup
@@ -53,6 +56,7 @@ template <> struct Traits<AZH_DTYPE_BF16> {
     typedef __bf16 elem;
     typedef bf16x8 afrag;     // 8 consecutive k of one output channel
     typedef bf16x4 quad;
+    typedef bf16x2 pair;
     static constexpr int KSTEP = 16;   // k per MFMA
     static constexpr int ESIZE = 2;
     __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -61,6 +65,7 @@ template <> struct Traits<AZH_DTYPE_F16> {
     typedef _Float16 elem;
     typedef f16x8 afrag;
     typedef f16x4 quad;
+    typedef f16x2 pair;
     static constexpr int KSTEP = 16;
     static constexpr int ESIZE = 2;
     __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -69,6 +74,7 @@ template <> struct Traits<AZH_DTYPE_F32> {
     typedef float elem;
     typedef float afrag;      // one k of one output channel
     typedef f32x4 quad;
+    typedef f32x2 pair;
     static constexpr int KSTEP = 2;
     static constexpr int ESIZE = 4;
     __device__ static f32x16 mfma(afrag a, afrag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -102,8 +108,7 @@ template <int DT> __device__ inline int unit_off(int row, int u)
 struct TowerArgs {
     const void *conv_w;      // packed A fragments, all tower layers back to back
     const void *head_w;      // packed A fragments of the fused policy+value 1x1 conv
-    const float *scale;      // [2B+1][128]  1/sqrt(var+eps)
-    const float *shift;      // [2B+1][128]  -mean*scale
+    const float *shift;      // [2B+1][128]  -mean/sqrt(var+eps); the scale 1/sqrt(var+eps) is folded into the packed weights
     const float *fc_w;       // [49]
     float fc_b;
     int blocks;
@@ -116,10 +121,23 @@ struct TowerArgs {
     float *values;           // [..], indexed by game
 };
 
-template <int DT, int NB>
-__device__ inline void conv_layer(const unsigned char *in, unsigned char *out, const unsigned char *skip,
-                                  const typename Traits<DT>::afrag *__restrict__ wp, int ksteps,
-                                  const float *__restrict__ scale, const float *__restrict__ shift,
+template <int V> struct IC { static constexpr int value = V; };
+
+template <int I, int N, typename Fn> __device__ inline void static_for(Fn &&fn)
+{
+    if constexpr (I < N) {
+        fn(IC<I>());
+        static_for<I + 1, N>(fn);
+    }
+}
+
+// One convolution layer for the workgroup's boards, KS k-steps per tap (compile time).
+// `in_off` / `out` / `skip` address the LDS images; lds is the start of dynamic LDS
+// (in_off is a multiple of the row size).
+template <int DT, int NB, int KS>
+__device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned char *out, const unsigned char *skip,
+                                  const typename Traits<DT>::afrag *__restrict__ wp,
+                                  typename Traits<DT>::afrag (&a)[4], const float *__restrict__ shift,
                                   const int (&vmask)[Geo<DT, NB>::NT], int wave, int lane)
 {
     typedef Traits<DT> Tr;
@@ -128,83 +146,134 @@ __device__ inline void conv_layer(const unsigned char *in, unsigned char *out, c
     constexpr int NT = G::NT;
     constexpr int USHIFT = DT == AZH_DTYPE_F32 ? 2 : 4;
     constexpr int UMASK = DT == AZH_DTYPE_F32 ? 31 : 15;
+    constexpr int TOTAL = 9 * KS;
     const int r = lane & 31, h = lane >> 5;
+    // accumulators start at the batch-norm shift of their channel (rows 8q + 4h + i of the
+    // wave's 32-channel tile), so the epilogue has no affine step left
     f32x16 acc[NT];
+    {
+        f32x16 init;
 #pragma unroll
-    for (int ct = 0; ct < NT; ct++)
+        for (int q = 0; q < 4; q++) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift + 32 * wave + 8 * q + 4 * h);
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            acc[ct][i] = 0.0f;
+            for (int i = 0; i < 4; i++)
+                init[4 * q + i] = t4[i];
+        }
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++)
+            acc[ct] = init;
+    }
 
-    // A fragments of this wave: index ((tap*ksteps + ks)*OCT + wave)*64 + lane
-    const afrag *wq = wp + wave * 64 + lane;
-    constexpr size_t S = OCT * 64;
-    const int total = 9 * ksteps;
+    // A fragments: wave-uniform base + one 32-bit lane offset; the fragment of step s sits
+    // s * OCT KiB further on.
+    const char *wbase = reinterpret_cast<const char *>(wp);
+    const unsigned lane_off = (unsigned)((wave * 64 + lane) * sizeof(afrag));
+    constexpr size_t STEP_BYTES = (size_t)OCT * 64 * sizeof(afrag);
+    // Steps >= TOTAL run on into the next layer's fragments (layers are contiguous in the
+    // packed buffer, which is padded at the end): the ring is already warm when the next
+    // layer starts.
+    auto load_a = [&](int step) {
+        const char *p = wbase + (size_t)step * STEP_BYTES;
+        return *reinterpret_cast<const afrag *>(p + lane_off);
+    };
 
-    // B-fragment addressing of the current tap: byte offset of the source row and its swizzle key
-    int rowoff[NT], rsw[NT];
-    auto set_rows = [&](int tap) {
+    // B fragments: rows[ct] = LDS byte address of the tap's source row with the row's
+    // swizzle key folded in, so the address of k-step ks is ONE xor away.  Off-board taps
+    // read the zero row, each lane at the slot its on-board row would have used: the lanes
+    // of a read stay on distinct banks whether or not their tap is on the board.
+    auto rows_for = [&](int tap, int (&dst)[NT]) {
         const int drow = (tap / 3 - 1) * 7 + (tap % 3 - 1);
 #pragma unroll
         for (int ct = 0; ct < NT; ct++) {
-            const int row = ((vmask[ct] >> tap) & 1) ? (ct * 32 + r + drow) : G::NC;
-            rowoff[ct] = row * G::ROWB;
-            rsw[ct] = row & UMASK;
+            const int row = ct * 32 + r + drow;
+            const int src = ((vmask[ct] >> tap) & 1) ? row : G::NC;
+            dst[ct] = (in_off + src * G::ROWB) | ((row & UMASK) << USHIFT);
         }
     };
-    auto load_b = [&](afrag (&bf)[NT], int ks) {
-        const int u = 2 * ks + h;
+    auto load_b = [&](afrag (&bf)[NT], const int (&rows)[NT], int ks) {
+        const int ux = (2 * ks + h) << USHIFT;
 #pragma unroll
         for (int ct = 0; ct < NT; ct++)
-            bf[ct] = *reinterpret_cast<const afrag *>(in + rowoff[ct] + ((u ^ rsw[ct]) << USHIFT));
+            bf[ct] = *reinterpret_cast<const afrag *>(lds + (rows[ct] ^ ux));
     };
 
-    // Software pipeline: while the MFMAs of step s run, the B fragments of step s+1 are
-    // already on their way from LDS and the A fragment of step s+2 from L2.
-    afrag b0[NT], b1[NT];
-    int tap = 0, ks = 0;
-    set_rows(0);
-    load_b(b0, 0);
-    afrag a0 = wq[0];
-    afrag a1 = wq[(size_t)(total > 1 ? 1 : 0) * S];
-    auto step = [&](afrag (&cur)[NT], afrag (&nxt)[NT], int s) {
-        if (s + 1 < total) {
-            if (++ks == ksteps) {
-                ks = 0;
-                set_rows(++tap);
+    // Software pipeline.  Step s = (tap, ks): while its MFMAs run, the B fragments of step
+    // s+1 are on their way from LDS and the A fragment of step s+4 from L2.  The body is
+    // straight-line code (compile-time phases, no branches) so that the waits the compiler
+    // inserts are exact counted waits and never drain the prefetch.
+    afrag b[2][NT];
+    int cur[NT], nxt[NT];
+    auto one_step = [&](auto ph_tag, auto par_tag, const int (&src)[NT], int ks_next, int s) {
+        constexpr int ph = decltype(ph_tag)::value, par = decltype(par_tag)::value;
+        load_b(b[par ^ 1], src, ks_next);
+        __builtin_amdgcn_sched_barrier(0);  // next step's LDS reads stay ahead of this step's MFMAs
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++)
+            acc[ct] = Tr::mfma(a[ph], b[par][ct], acc[ct]);
+        a[ph] = load_a(s + 4);
+    };
+    rows_for(0, cur);
+    load_b(b[0], cur, 0);
+
+    if constexpr (TOTAL <= 18) {
+        // few steps (the 4-plane input layer): everything unrolled
+        static_for<0, 9>([&](auto tap_tag) {
+            constexpr int tap = decltype(tap_tag)::value;
+            rows_for(tap < 8 ? tap + 1 : 8, nxt);
+            static_for<0, KS>([&](auto ks_tag) {
+                constexpr int ks = decltype(ks_tag)::value, s = tap * KS + ks;
+                if constexpr (ks + 1 < KS)
+                    one_step(IC<(s & 3)>(), IC<(s & 1)>(), cur, ks + 1, s);
+                else
+                    one_step(IC<(s & 3)>(), IC<(s & 1)>(), nxt, 0, s);
+            });
+#pragma unroll
+            for (int ct = 0; ct < NT; ct++)
+                cur[ct] = nxt[ct];
+        });
+    } else {
+        static_assert(KS % 4 == 0, "k-steps per tap must be a multiple of the A ring");
+        constexpr int CH = KS <= 8 ? KS : 4;   // unrolled steps per chunk
+        for (int tap = 0; tap < 9; tap++) {
+            rows_for(tap < 8 ? tap + 1 : 8, nxt);
+            for (int k0 = 0; k0 < KS; k0 += CH) {
+                const bool last_chunk = k0 + CH == KS;
+                int tail[NT];  // source rows of the chunk's last prefetch
+#pragma unroll
+                for (int ct = 0; ct < NT; ct++)
+                    tail[ct] = last_chunk ? nxt[ct] : cur[ct];
+                const int tail_ks = last_chunk ? 0 : k0 + CH;
+                const int s0 = tap * KS + k0;
+                static_for<0, CH>([&](auto j_tag) {
+                    constexpr int j = decltype(j_tag)::value;
+                    if constexpr (j + 1 < CH)
+                        one_step(IC<(j & 3)>(), IC<(j & 1)>(), cur, k0 + j + 1, s0 + j);
+                    else
+                        one_step(IC<(j & 3)>(), IC<(j & 1)>(), tail, tail_ks, s0 + j);
+                });
             }
-            load_b(nxt, ks);
-        }
-        const afrag a2 = wq[(size_t)(s + 2 < total ? s + 2 : total - 1) * S];
 #pragma unroll
-        for (int ct = 0; ct < NT; ct++)
-            acc[ct] = Tr::mfma(a0, cur[ct], acc[ct]);
-        a0 = a1;
-        a1 = a2;
-    };
-    int s = 0;
-    for (; s + 1 < total; s += 2) {
-        step(b0, b1, s);
-        step(b1, b0, s + 1);
+            for (int ct = 0; ct < NT; ct++)
+                cur[ct] = nxt[ct];
+        }
     }
-    if (s < total)
-        step(b0, b1, s);
 
-    // epilogue: bn, (+skip), relu, convert, write [cell][channel]
-    float sc[16], sh[16];
+    // the ring now holds steps TOTAL .. TOTAL+3 at slots (TOTAL + i) % 4: rotate so that
+    // slot i is the next layer's step i
+    if constexpr (TOTAL % 4 != 0) {
+        afrag t[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int ch = 32 * wave + 8 * q + 4 * h;
-        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(scale + ch);
-        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift + ch);
+        for (int i = 0; i < 4; i++)
+            t[i] = a[(TOTAL + i) % 4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            sc[4 * q + i] = s4[i];
-            sh[4 * q + i] = t4[i];
-        }
+        for (int i = 0; i < 4; i++)
+            a[i] = t[i];
     }
+
+    // epilogue: (+skip), relu, convert, write [cell][channel]
 #pragma unroll
-    for (int ct = 0; ct < G::NT; ct++) {
+    for (int ct = 0; ct < NT; ct++) {
         const int cell = ct * 32 + r;
         if (cell < G::NC) {
 #pragma unroll
@@ -213,7 +282,7 @@ __device__ inline void conv_layer(const unsigned char *in, unsigned char *out, c
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    v[i] = __builtin_fmaf(acc[ct][4 * q + i], sc[4 * q + i], sh[4 * q + i]);
+                    v[i] = acc[ct][4 * q + i];
                 if constexpr (DT == AZH_DTYPE_F32) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -224,18 +293,24 @@ __device__ inline void conv_layer(const unsigned char *in, unsigned char *out, c
                     }
                 } else {
                     typedef typename Tr::quad quad;
+                    typedef typename Tr::pair pair;
                     const int off = unit_off<DT>(cell, ch >> 3) + ((ch & 7) << 1);
                     if (skip) {
-                        const quad s = *reinterpret_cast<const quad *>(skip + off);
+                        const quad sk = *reinterpret_cast<const quad *>(skip + off);
 #pragma unroll
                         for (int i = 0; i < 4; i++)
-                            v[i] += (float)s[i];
+                            v[i] += (float)sk[i];
                     }
-                    quad o;
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        o[i] = (typename Tr::elem)(v[i] > 0.0f ? v[i] : 0.0f);
-                    *reinterpret_cast<quad *>(out + off) = o;
+                        v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                    f32x2 lo, hi;
+                    lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
+                    const pair plo = __builtin_convertvector(lo, pair), phi = __builtin_convertvector(hi, pair);
+                    uint2 packed;
+                    packed.x = __builtin_bit_cast(unsigned, plo);
+                    packed.y = __builtin_bit_cast(unsigned, phi);
+                    *reinterpret_cast<uint2 *>(out + off) = packed;
                 }
             }
         }
@@ -315,15 +390,19 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w);
     const size_t l0 = (size_t)9 * G::KSTEPS_IN * OCT * 64;
     const size_t lf = (size_t)9 * G::KSTEPS_FULL * OCT * 64;
-    conv_layer<DT, NB>(buf0, buf1, nullptr, wp, G::KSTEPS_IN, A.scale, A.shift, vmask, wave, lane);
+    afrag aring[4];  // A-fragment ring, kept warm across layers
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        aring[i] = wp[(size_t)i * OCT * 64 + wave * 64 + lane];
+    conv_layer<DT, NB, G::KSTEPS_IN>(smem, 0, buf1, nullptr, wp, aring, A.shift, vmask, wave, lane);
     __syncthreads();
     wp += l0;
     for (int b = 0; b < A.blocks; b++) {
-        const float *s1 = A.scale + (size_t)(1 + 2 * b) * F, *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer<DT, NB>(buf1, buf0, nullptr, wp, G::KSTEPS_FULL, s1, t1, vmask, wave, lane);
+        const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
+        conv_layer<DT, NB, G::KSTEPS_FULL>(smem, G::IMG, buf0, nullptr, wp, aring, t1, vmask, wave, lane);
         __syncthreads();
         wp += lf;
-        conv_layer<DT, NB>(buf0, buf1, buf1, wp, G::KSTEPS_FULL, s1 + F, t1 + F, vmask, wave, lane);
+        conv_layer<DT, NB, G::KSTEPS_FULL>(smem, 0, buf1, buf1, wp, aring, t1 + F, vmask, wave, lane);
         __syncthreads();
         wp += lf;
     }
@@ -401,9 +480,10 @@ template <> inline uint16_t cvt_elem<uint16_t>(float f, int dt) { return dt == A
 template <> inline float cvt_elem<float>(float f, int) { return f; }
 
 // Pack W[tap][cin][128] (HWIO, tap = 3*i + j) into A-fragment order.
+// `scale` (per output column, may be null) is multiplied in before the conversion.
 template <typename T>
-static void pack_conv(const float *w, int cin, int taps, int ksteps, int kstep, int octiles, int ocols,
-                      int dt, std::vector<T> &out)
+static void pack_conv(const float *w, const float *scale, int cin, int taps, int ksteps, int kstep, int octiles,
+                      int ocols, int dt, std::vector<T> &out)
 {
     const int per_lane = kstep / 2;  // k elements per lane per MFMA
     for (int tap = 0; tap < taps; tap++)
@@ -415,7 +495,7 @@ static void pack_conv(const float *w, int cin, int taps, int ksteps, int kstep, 
                         const int oc = 32 * ot + (lane & 31);
                         float v = 0.0f;
                         if (c < cin && oc < ocols)
-                            v = w[((size_t)tap * cin + c) * ocols + oc];
+                            v = w[((size_t)tap * cin + c) * ocols + oc] * (scale ? scale[oc] : 1.0f);
                         out.push_back(cvt_elem<T>(v, dt));
                     }
 }
@@ -432,7 +512,8 @@ using namespace azh;
 struct azh_net {
     int blocks = 0, filters = 0;
     std::vector<float> conv_flat;  // host copy, reference order
-    float *d_scale = nullptr, *d_shift = nullptr, *d_fcw = nullptr;
+    std::vector<float> scale;      // [2B+1][128] 1/sqrt(var+eps), folded into the packed weights
+    float *d_shift = nullptr, *d_fcw = nullptr;
     float fc_b = 0.0f;
     NetDtypeBuffers bufs[3];
 };
@@ -461,18 +542,24 @@ static int net_pack(azh_net *net, int dt)
     };
     if (dt == AZH_DTYPE_F32) {
         std::vector<float> cw, hw;
-        pack_conv<float>(p, 4, 9, ks_in, kstep, OCT, F, dt, cw);
+        const float *sc = net->scale.data();
+        pack_conv<float>(p, sc, 4, 9, ks_in, kstep, OCT, F, dt, cw);
         for (int l = 0; l < 2 * B; l++)
-            pack_conv<float>(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, F, 9, ks_full, kstep, OCT, F, dt, cw);
-        pack_conv<float>(head.data(), F, 1, ks_full, kstep, 1, 32, dt, hw);
+            pack_conv<float>(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, sc + (size_t)(l + 1) * F, F, 9, ks_full, kstep,
+                             OCT, F, dt, cw);
+        cw.resize(cw.size() + 4 * OCT * 64, 0.0f);  // the A ring reads four steps past the last layer
+        pack_conv<float>(head.data(), nullptr, F, 1, ks_full, kstep, 1, 32, dt, hw);
         if (upload(cw.data(), cw.size() * 4, &net->bufs[dt].conv_w)) return -1;
         if (upload(hw.data(), hw.size() * 4, &net->bufs[dt].head_w)) return -1;
     } else {
         std::vector<uint16_t> cw, hw;
-        pack_conv<uint16_t>(p, 4, 9, ks_in, kstep, OCT, F, dt, cw);
+        const float *sc = net->scale.data();
+        pack_conv<uint16_t>(p, sc, 4, 9, ks_in, kstep, OCT, F, dt, cw);
         for (int l = 0; l < 2 * B; l++)
-            pack_conv<uint16_t>(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, F, 9, ks_full, kstep, OCT, F, dt, cw);
-        pack_conv<uint16_t>(head.data(), F, 1, ks_full, kstep, 1, 32, dt, hw);
+            pack_conv<uint16_t>(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, sc + (size_t)(l + 1) * F, F, 9, ks_full,
+                                kstep, OCT, F, dt, cw);
+        cw.resize(cw.size() + 4 * OCT * 64 * 8, 0);  // the A ring reads four steps past the last layer
+        pack_conv<uint16_t>(head.data(), nullptr, F, 1, ks_full, kstep, 1, 32, dt, hw);
         if (upload(cw.data(), cw.size() * 2, &net->bufs[dt].conv_w)) return -1;
         if (upload(hw.data(), hw.size() * 2, &net->bufs[dt].head_w)) return -1;
     }
@@ -506,10 +593,9 @@ extern "C" int azh_net_create(int blocks, int filters, const float *conv_flat, c
         }
     const float *fc = conv_flat + n_conv - 50;
     net->fc_b = fc[49];
-    AZH_HIP(hipMalloc((void **)&net->d_scale, scale.size() * 4));
+    net->scale = scale;
     AZH_HIP(hipMalloc((void **)&net->d_shift, shift.size() * 4));
     AZH_HIP(hipMalloc((void **)&net->d_fcw, 49 * 4));
-    AZH_HIP(hipMemcpy(net->d_scale, scale.data(), scale.size() * 4, hipMemcpyHostToDevice));
     AZH_HIP(hipMemcpy(net->d_shift, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
     AZH_HIP(hipMemcpy(net->d_fcw, fc, 49 * 4, hipMemcpyHostToDevice));
     *out = net;
@@ -524,7 +610,6 @@ extern "C" void azh_net_destroy(azh_net *net)
         if (b.conv_w) (void)hipFree(b.conv_w);
         if (b.head_w) (void)hipFree(b.head_w);
     }
-    if (net->d_scale) (void)hipFree(net->d_scale);
     if (net->d_shift) (void)hipFree(net->d_shift);
     if (net->d_fcw) (void)hipFree(net->d_fcw);
     delete net;
@@ -572,7 +657,6 @@ int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, 
     TowerArgs a;
     a.conv_w = net->bufs[dtype].conv_w;
     a.head_w = net->bufs[dtype].head_w;
-    a.scale = net->d_scale;
     a.shift = net->d_shift;
     a.fc_w = net->d_fcw;
     a.fc_b = net->fc_b;
