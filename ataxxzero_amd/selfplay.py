@@ -68,26 +68,64 @@ def select_device(index):
 
 
 class SelfPlay:
-    """`games` concurrent MCTS self-play games on one GPU with the built-in net."""
+    """`games` concurrent MCTS self-play games on one GPU with the built-in net.
+
+    With `streams` = 2 the games are split into two half-batches, each with its own engine
+    and HIP stream, sharing one set of packed weights — the reference's double buffer
+    (cpp/self_play_client.cpp:593-600, two fill buffers of `buffer_entries` rows): while one
+    half runs its tree kernels or the tail of its tower launch, the other half's tower fills
+    the idle CUs.  The halves are independent game shards (distinct Philox streams)."""
 
     def __init__(self, conv_weights, bn_params, games, visits, dtype="bf16", seed=DEFAULT_SEED,
-                 fen=START_FEN_SELFPLAY, **cfg):
+                 fen=START_FEN_SELFPLAY, streams=1, **cfg):
         self.dtype = link.DTYPES[dtype]
         self.net = link.Net(conv_weights, bn_params, model.BN_EPSILON)
-        self.engine = link.Engine(make_config(games, visits, seed=seed, fen=fen, **cfg))
+        if streams < 1 or games % streams:
+            raise ValueError("games (%d) must be a positive multiple of streams (%d)" % (games, streams))
+        self.engines = [link.Engine(make_config(games // streams, visits, seed=seed + 1000003 * i, fen=fen, **cfg))
+                        for i in range(streams)]
+        self.engine = self.engines[0]
         self.games = games
 
     def run(self, iterations):
-        self.engine.run(self.net, iterations, self.dtype)
+        if len(self.engines) == 1:
+            self.engine.run(self.net, iterations, self.dtype)
+            return
+        for _ in range(iterations):
+            for e in self.engines:
+                e.run(self.net, 1, self.dtype)
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
 
     def drain(self):
-        return self.engine.drain_json()
+        lines = []
+        for e in self.engines:
+            lines += e.drain_json()
+        return lines
 
     def stats(self):
-        return self.engine.stats()
+        total = {}
+        for e in self.engines:
+            for k, v in e.stats().items():
+                total[k] = total.get(k, 0) + v
+        return total
+
+    def timing_reset(self, enable=True):
+        for e in self.engines:
+            e.timing_reset(enable)
+
+    def timing(self):
+        total = {}
+        for e in self.engines:
+            for k, v in e.timing().items():
+                total[k] = total.get(k, 0) + v
+        return total
 
     def close(self):
-        self.engine.close()
+        for e in self.engines:
+            e.close()
         self.net.close()
 
 

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--chunk", type=int, default=250, help="iterations between finished-game drains")
+    ap.add_argument("--streams", type=int, default=1, help="half-batches in flight per GPU (the reference's double buffer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -90,8 +91,7 @@ def main():
 
     conv, bn = model.random_init(args.blocks, 128, seed=1)
     sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
-                           seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank))
-    eng = sp.engine
+                           seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank), streams=args.streams)
 
     def run(iters):
         done = 0
@@ -104,17 +104,17 @@ def main():
         return finished
 
     run(args.warmup)
-    eng.sync()
+    sp.sync()
     group.barrier()
-    st0 = eng.stats()
-    eng.timing_reset(True)
+    st0 = sp.stats()
+    sp.timing_reset(True)
     t0 = time.perf_counter()
     finished = run(args.steps)
-    eng.sync()
+    sp.sync()
     t1 = time.perf_counter()
     group.barrier()
-    st1 = eng.stats()
-    tm = eng.timing()
+    st1 = sp.stats()
+    tm = sp.timing()
     d = {k: st1[k] - st0[k] for k in st1}
     steps_total, t_max, rate = distrib.aggregate(group, d["steps"], t1 - t0)
     evals_total = group.reduce(d["nn_evals"], "sum")
@@ -123,8 +123,8 @@ def main():
 
     if group.rank == 0:
         flops = model.flops_per_eval(args.blocks, 128)
-        it = max(tm["iterations"], 1)
-        frac_timed = it / float(args.steps)
+        it = max(tm["iterations"], 1)   # launches recorded (per half-batch when streams > 1)
+        frac_timed = it / float(args.steps * args.streams)
         net_s = tm["net_ms"] * 1e-3
         achieved_tf = d["nn_evals"] * frac_timed * flops / net_s / 1e12 if net_s > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -139,14 +139,15 @@ def main():
             "config": {"workload": "%d concurrent self-play games per GPU, %d sims/move, %dx128 conv net, %s "
                                    "(per-GPU shard of BASELINE configs[2]; configs[1] at the metric's 400 sims)"
                                    % (args.games, args.visits, args.blocks, args.dtype),
-                       "games_per_gpu": args.games, "visits": args.visits, "net": "%dx128" % args.blocks,
+                       "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
+                       "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},
             "nn_evals_per_s": evals_total / t_max, "plies_per_s": plies_total / t_max,
             "games_per_s": games_total / t_max,
             "games_per_s_steady_state_est": (plies_total / t_max) / 182.4 if plies_total else None,
             "roofline": {"bound": "mfma", "kernel": "k_tower<%s>" % args.dtype, "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": None,
-                         "avg_launch_ms": tm["net_ms"] / it, "evals_per_launch": d["nn_evals"] / float(args.steps),
+                         "avg_launch_ms": tm["net_ms"] / it, "evals_per_launch": d["nn_evals"] / float(args.steps * args.streams),
                          "flops_per_eval": flops},
             "tree_roofline": {"bound": "hbm", "kernels": "k_select+k_compact / k_backup+k_advance",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS,

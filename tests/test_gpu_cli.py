@@ -1,0 +1,133 @@
+"""Drop-in surface on the GPU: the two CLIs, the reference's four-symbol ABI (link.py) and
+the looper.py contract (append, flush, stop on SIGTERM, per-process file index)."""
+import ctypes
+import json
+import os
+import signal
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from ataxxzero_amd import link, model, selfplay
+from oracle import net_oracle
+from oracle import oracle_lib as orc
+from tests.helpers import replay_game_entry
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_abi_host_evaluated_selfplay(tmp_path):
+    """The accelerated_generate_games.py host loop (:26-37, :54-83) against the GPU library:
+    get_workload -> evaluate the (B,7,7,4) buffer on the host -> complete_workload."""
+    B = 16
+    conv, bn = model.random_init(1, 128, seed=6)
+    out = str(tmp_path / "games.json")
+    bufs = [np.zeros((B, 7, 7, 4), dtype=np.float32) for _ in (0, 1)]
+    link.launch_threads(out.encode(), 10, ctypes.c_void_p(bufs[0].ctypes.data), ctypes.c_void_p(bufs[1].ctypes.data),
+                        B, 2 * B)
+    try:
+        seen_rows = 0
+        for _ in range(1600):
+            w = link.get_workload()
+            assert w in (0, 1)
+            feats = bufs[w]
+            assert set(np.unique(feats)) <= {0.0, 1.0}
+            live = feats[:, :, :, 0].sum(axis=(1, 2)) == 49  # plane 0 is all ones on real rows
+            seen_rows += int(live.sum())
+            # rows carry the 4 blockers of the self-play start (cpp/self_play_client.cpp:23,198-200)
+            assert (feats[live][:, :, :, 3].sum(axis=(1, 2)) == 4).all()
+            p, v = net_oracle.forward(conv, bn, feats, dtype=np.float32)
+            p = np.ascontiguousarray(p, dtype=np.float32)
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            link.complete_workload(w, ctypes.c_void_p(p.ctypes.data), ctypes.c_void_p(v.ctypes.data))
+        assert seen_rows > 1000
+    finally:
+        link.shutdown()
+    lines = [l for l in open(out).read().split("\n") if l.strip()]
+    assert len(lines) >= 3
+    for line in lines:
+        entry = json.loads(line)
+        assert list(entry) == ["boards", "dists", "moves", "result"] and entry["result"] in (1, 2)
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+    # relaunch after shutdown works (shutdown clears state for another run, :740-749) and appends
+    link.launch_threads(out.encode(), 4, ctypes.c_void_p(bufs[0].ctypes.data), ctypes.c_void_p(bufs[1].ctypes.data), B, 2 * B)
+    link.shutdown()
+    assert len([l for l in open(out).read().split("\n") if l.strip()]) == len(lines)
+
+
+def test_accelerated_generate_games_cli_appends_and_stops_on_sigterm(tmp_path):
+    conv, bn = model.random_init(1, 128, seed=3)
+    net_path = str(tmp_path / "model-001.npy")
+    model.save_model(net_path, conv, bn)
+    games_path = str(tmp_path / "model-001-0.json")
+    with open(games_path, "w") as f:
+        f.write('{"pre-existing": true}\n')  # append mode must keep it (looper.py:24-30)
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "accelerated_generate_games.py"), "--network", net_path,
+                             "--output-games", games_path, "--visits", "8", "--buffer-size", "64"],
+                            cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    deadline = time.time() + 240
+    while time.time() < deadline:
+        time.sleep(1.0)
+        if sum(1 for l in open(games_path) if l.strip()) >= 30 or proc.poll() is not None:
+            break
+    assert proc.poll() is None, proc.stdout.read().decode()[-2000:]
+    t0 = time.time()
+    proc.send_signal(signal.SIGTERM)
+    out, _ = proc.communicate(timeout=20)
+    assert time.time() - t0 < 2.0, "looper.py waits 2 s before SIGKILL (looper.py:59-64)"
+    text = out.decode()
+    assert "Exiting cleanly" in text and proc.returncode == 0
+    lines = [l for l in open(games_path) if l.strip()]
+    assert lines[0].strip() == '{"pre-existing": true}' and len(lines) >= 31
+    for line in lines[1:8]:
+        entry = json.loads(line)
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+        # train.py:43-77 consumer assumptions: x moves on even plies, dists keyed by UAI strings
+        assert all(isinstance(k, str) and len(k) in (2, 4) for d in entry["dists"] for k in d)
+
+
+def test_generate_games_random_play_cli(tmp_path):
+    path = str(tmp_path / "random.json")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "generate_games.py"), "--random-play", "--output-games", path,
+                          "--game-count", "300"], cwd=ROOT, capture_output=True, timeout=240)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert b"Doing random play" in res.stdout and b"Done generating games." in res.stdout
+    lines = [l for l in open(path) if l.strip()]
+    assert len(lines) == 300
+    plies = []
+    for line in lines[:60]:
+        assert '", "' not in line and "], [" in line  # json.dump default separators (generate_games.py:134)
+        entry = json.loads(line)
+        assert list(entry) == ["boards", "moves", "result"] and entry["result"] in (1, 2)
+        # reference move values: ["c",[x,y]] / [[x0,y0],[x1,y1]] (ataxx_rules.py:108-127 via json)
+        uai = []
+        for m in entry["moves"]:
+            sq = lambda xy: "abcdefg"[xy[0]] + str(7 - xy[1])
+            uai.append(sq(m[1]) if m[0] == "c" else sq(m[0]) + sq(m[1]))
+        e2 = {"boards": entry["boards"], "moves": uai}
+        assert replay_game_entry(e2, orc.START_FEN_PLAIN) == entry["result"]
+        plies.append(len(uai))
+    assert 100 < np.mean(plies) < 260  # reference random play averages 182 plies
+
+
+def test_two_half_batches_match_two_independent_engines():
+    conv, bn = model.random_init(1, 128, seed=9)
+    sp = selfplay.SelfPlay(conv, bn, games=64, visits=12, dtype="f32", seed=5, streams=2)
+    sp.run(120)
+    sp.sync()
+    ref = []
+    for i in range(2):
+        e = link.Engine(selfplay.make_config(32, 12, seed=5 + 1000003 * i))
+        e.run(sp.net, 120, link.DTYPE_F32)
+        e.sync()
+        ref.append(e)
+    for a, b in zip(sp.engines, ref):
+        for g in range(32):
+            assert a.game_state(g).as_tuple() == b.game_state(g).as_tuple()
+            for x, y in zip(a.tree(g), b.tree(g)):
+                assert (x == y).all()
+    sp.close()
