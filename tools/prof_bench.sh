@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 passes over bench.py itself (run on the GPU box from the repo root):
+# kernel trace + stats of the default bench command, then PMC passes for the dominant kernel.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/prof_bench
+ARGS=${ARGS:---steps 300 --warmup 200 --no-cpu-baseline}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -- python3 $R/bench.py $ARGS > $OUT/pmc1.log 2>&1 || exit 2
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc2 -- python3 $R/bench.py $ARGS > $OUT/pmc2.log 2>&1 || exit 3
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc3 -- python3 $R/bench.py $ARGS > $OUT/pmc3.log 2>&1 || exit 4
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc4 -- python3 $R/bench.py $ARGS > $OUT/pmc4.log 2>&1 || exit 5
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc5 -- python3 $R/bench.py $ARGS > $OUT/pmc5.log 2>&1 || exit 6
+# keep the merge small: the per-dispatch counter CSVs are large; summarise on the box
+python3 $R/tools/prof_summary.py $OUT k_tower > $OUT/summary_k_tower.txt 2>&1
+for k in k_select k_backup k_advance k_compact; do python3 $R/tools/prof_summary.py $OUT $k > $OUT/summary_$k.txt 2>&1; done
+find $OUT -name "*_counter_collection.csv" -delete
+find $OUT -name "*_kernel_trace.csv" -size +8M -delete
+ls -la $OUT
