@@ -30,4 +30,4 @@ int azh_require_device(void);
 // net_kernels.hip
 int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                    const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                   float *d_values, hipStream_t stream);
+                   float *d_values, hipStream_t stream, unsigned long long *d_stamps = nullptr);

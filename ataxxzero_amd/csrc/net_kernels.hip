@@ -19,14 +19,17 @@
 // 8-byte runs straight back into the [cell][channel] LDS image that the next
 // layer reads as its B operand: no transpose, no global round trip.
 //
-// A workgroup = 4 waves = BOARDS boards (6 for 16-bit types, 3 for f32); wave w
-// owns output channels [32w, 32w+32).  LDS holds two activation images
-// [cells + 1 zero row][128 ch]; taps that fall off the board read the zero row.
-// Rows are 256 B (16-bit) / 512 B (f32) — a multiple of the LDS bank row — so
-// 16-byte chunks are XOR-swizzled with the cell index to keep the 32 cells of a
-// B-fragment read on distinct banks.
+// A workgroup = 4 waves = BOARDS boards; wave w owns output channels [32w, 32w+32).
+// LDS holds two activation images laid out [channel unit][cell slot]: a unit is 8
+// channels = 16 B (16-bit types) or one f32 channel, and the slots of a unit are the
+// workgroup's cells followed by a few always-zero slots.  The 32 cells of one B-fragment
+// read are therefore 512 contiguous bytes (no bank conflicts, no swizzle) and moving to
+// the next k-step is an immediate offset on the ds_read: the k-loop spends no VALU on
+// addresses.  Taps that fall off the board read a zero slot with the same residue mod
+// 8/16 as the cell they replace, so they stay off the other lanes' banks.
 // Weights are pre-packed on the host in exact A-fragment order (1 KiB per
-// wave-instruction), streamed from L2 with a two-deep register prefetch.
+// wave-instruction, batch-norm scale folded in) and streamed from L2 through a
+// four-deep register ring that stays warm across layers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -88,22 +91,28 @@ template <int DT, int NB> struct Geo {
     static constexpr int BOARDS = NB;
     static constexpr int NC = 49 * BOARDS;             // real cells per workgroup
     static constexpr int NT = (NC + 31) / 32;          // 32-cell MFMA column tiles
-    static constexpr int ROWB = F * Tr::ESIZE;         // bytes per cell row
-    static constexpr int IMG = (NC + 1) * ROWB;        // one activation image (+ zero row)
-    static constexpr int STAGE_OFF = 2 * IMG;          // f32 value-cell scratch
-    static constexpr int LDS_BYTES = 2 * IMG + NC * 4;
+    static constexpr int Z = (DT != AZH_DTYPE_F32 && NB == 6) ? 16 : 8;   // zero slots (power of two)
+    static constexpr int NSLOT = NC + Z;
+    static constexpr int UB = DT == AZH_DTYPE_F32 ? 4 : 16;               // bytes of one unit in one slot
+    static constexpr int NUNIT = F * Tr::ESIZE / UB;                        // units per image
+    static constexpr int CS = NSLOT * UB;              // byte stride between units
+    static constexpr int IMG = NUNIT * CS;             // one activation image
+    static constexpr int VCELL_OFF = NB * 833 * 4;     // value-cell scratch behind the staged logits (image 0)
+    static constexpr int LDS_BYTES = 2 * IMG;
     static constexpr int KSTEPS_FULL = F / Tr::KSTEP;  // k-steps per tap, 128-channel input
     static constexpr int KSTEPS_IN = (Tr::KSTEP >= 4) ? 1 : 4 / Tr::KSTEP;  // 4 input planes
+    static_assert(VCELL_OFF + NC * 4 <= IMG, "staging area must fit in one image");
+    // slot of cell c (c may be a neighbour index that fell off its board or a pad lane)
+    __device__ static int zero_slot(int c) { return NC + ((c - NC) & (Z - 1)); }
+    // byte offset of (slot, unit, byte) inside an image
+    __device__ static int off(int slot, int unit, int byte = 0) { return unit * CS + slot * UB + byte; }
+    // 16-bit types: channel ch lives in unit ch/8 at byte 2*(ch%8); f32: unit ch
+    __device__ static int ch_off(int slot, int ch)
+    {
+        if constexpr (DT == AZH_DTYPE_F32) return off(slot, ch);
+        else return off(slot, ch >> 3, (ch & 7) << 1);
+    }
 };
-
-// Byte offset of the 16-byte (16-bit types) or 4-byte (f32) unit `u` of row `row`.
-template <int DT> __device__ inline int unit_off(int row, int u)
-{
-    if constexpr (DT == AZH_DTYPE_F32)
-        return row * (F * 4) + ((u ^ (row & 31)) << 2);
-    else
-        return row * (F * 2) + ((u ^ (row & 15)) << 4);
-}
 
 struct TowerArgs {
     const void *conv_w;      // packed A fragments, all tower layers back to back
@@ -119,6 +128,7 @@ struct TowerArgs {
     unsigned long long blockers;
     float *logits;           // [..][833], indexed by game
     float *values;           // [..], indexed by game
+    unsigned long long *stamps;  // diagnostic build only: [workgroup][wave][128] s_memtime stamps
 };
 
 template <int V> struct IC { static constexpr int value = V; };
@@ -134,36 +144,72 @@ template <int I, int N, typename Fn> __device__ inline void static_for(Fn &&fn)
 // One convolution layer for the workgroup's boards, KS k-steps per tap (compile time).
 // `in_off` / `out` / `skip` address the LDS images; lds is the start of dynamic LDS
 // (in_off is a multiple of the row size).
-template <int DT, int NB, int KS>
+__device__ inline unsigned long long stamp_now()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <int DT, int NB, int KS, bool STAMP = false>
 __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned char *out, const unsigned char *skip,
                                   const typename Traits<DT>::afrag *__restrict__ wp,
-                                  typename Traits<DT>::afrag (&a)[4], const float *__restrict__ shift,
-                                  const int (&vmask)[Geo<DT, NB>::NT], int wave, int lane)
+                                  typename Traits<DT>::afrag (&a)[4], f32x16 &sh, const float *__restrict__ shift_next,
+                                  const int (&vmask)[Geo<DT, NB>::NT], int wave, int lane,
+                                  unsigned long long *st = nullptr)
 {
     typedef Traits<DT> Tr;
     typedef Geo<DT, NB> G;
     typedef typename Tr::afrag afrag;
     constexpr int NT = G::NT;
-    constexpr int USHIFT = DT == AZH_DTYPE_F32 ? 2 : 4;
-    constexpr int UMASK = DT == AZH_DTYPE_F32 ? 31 : 15;
     constexpr int TOTAL = 9 * KS;
     const int r = lane & 31, h = lane >> 5;
-    // accumulators start at the batch-norm shift of their channel (rows 8q + 4h + i of the
-    // wave's 32-channel tile), so the epilogue has no affine step left
+    // Accumulators start at the batch-norm shift of their channel (rows 8q + 4h + i of the
+    // wave's 32-channel tile) plus, for the second conv of a block, the residual input read
+    // from the output image (still intact: this layer only writes it in its epilogue).  The
+    // epilogue then has no affine step and no read-modify-write left.  `sh` was loaded
+    // during the previous layer; the next layer's shift is fetched behind the k-loop.
     f32x16 acc[NT];
-    {
-        f32x16 init;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift + 32 * wave + 8 * q + 4 * h);
+    for (int ct = 0; ct < NT; ct++)
+        acc[ct] = sh;
+    if (skip) {
+        // branch-free: pad lanes read a zero slot, so all reads of the wave issue back to back
+        typename Tr::quad sk[NT][4];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                init[4 * q + i] = t4[i];
+        for (int ct = 0; ct < NT; ct++) {
+            const int cell = ct * 32 + r;
+            const int slot = cell < G::NC ? cell : G::zero_slot(cell);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int ch = 32 * wave + 8 * q + 4 * h;
+                if constexpr (DT == AZH_DTYPE_F32) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        sk[ct][q][i] = *reinterpret_cast<const float *>(skip + G::ch_off(slot, ch + i));
+                } else {
+                    sk[ct][q] = *reinterpret_cast<const typename Tr::quad *>(skip + G::ch_off(slot, ch));
+                }
+            }
         }
 #pragma unroll
         for (int ct = 0; ct < NT; ct++)
-            acc[ct] = init;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc[ct][4 * q + i] += (float)sk[ct][q][i];
     }
+    auto fetch_shift = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift_next + 32 * wave + 8 * q + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                sh[4 * q + i] = t4[i];
+        }
+    };
 
     // A fragments: wave-uniform base + one 32-bit lane offset; the fragment of step s sits
     // s * OCT KiB further on.
@@ -178,24 +224,22 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
         return *reinterpret_cast<const afrag *>(p + lane_off);
     };
 
-    // B fragments: rows[ct] = LDS byte address of the tap's source row with the row's
-    // swizzle key folded in, so the address of k-step ks is ONE xor away.  Off-board taps
-    // read the zero row, each lane at the slot its on-board row would have used: the lanes
-    // of a read stay on distinct banks whether or not their tap is on the board.
+    // B fragments: rows[ct] = LDS byte address of the tap's source slot for this lane's k
+    // half; k-step ks is an immediate 2*CS*ks further on.  Off-board taps (and pad lanes)
+    // read a zero slot of the same residue.
     auto rows_for = [&](int tap, int (&dst)[NT]) {
         const int drow = (tap / 3 - 1) * 7 + (tap % 3 - 1);
 #pragma unroll
         for (int ct = 0; ct < NT; ct++) {
-            const int row = ct * 32 + r + drow;
-            const int src = ((vmask[ct] >> tap) & 1) ? row : G::NC;
-            dst[ct] = (in_off + src * G::ROWB) | ((row & UMASK) << USHIFT);
+            const int c = ct * 32 + r + drow;
+            const int slot = ((vmask[ct] >> tap) & 1) ? c : G::zero_slot(c);
+            dst[ct] = in_off + h * G::CS + slot * G::UB;
         }
     };
     auto load_b = [&](afrag (&bf)[NT], const int (&rows)[NT], int ks) {
-        const int ux = (2 * ks + h) << USHIFT;
 #pragma unroll
         for (int ct = 0; ct < NT; ct++)
-            bf[ct] = *reinterpret_cast<const afrag *>(lds + (rows[ct] ^ ux));
+            bf[ct] = *reinterpret_cast<const afrag *>(lds + rows[ct] + ks * (2 * G::CS));
     };
 
     // Software pipeline.  Step s = (tap, ks): while its MFMAs run, the B fragments of step
@@ -215,6 +259,7 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
     };
     rows_for(0, cur);
     load_b(b[0], cur, 0);
+    if constexpr (STAMP) st[0] = stamp_now();
 
     if constexpr (TOTAL <= 18) {
         // few steps (the 4-plane input layer): everything unrolled
@@ -259,6 +304,8 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
         }
     }
 
+    if constexpr (STAMP) st[1] = stamp_now();
+    fetch_shift();  // next layer's shift: in flight behind the epilogue and the barrier
     // the ring now holds steps TOTAL .. TOTAL+3 at slots (TOTAL + i) % 4: rotate so that
     // slot i is the next layer's step i
     if constexpr (TOTAL % 4 != 0) {
@@ -271,7 +318,7 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
             a[i] = t[i];
     }
 
-    // epilogue: (+skip), relu, convert, write [cell][channel]
+    // epilogue: relu, convert, write [cell][channel]
 #pragma unroll
     for (int ct = 0; ct < NT; ct++) {
         const int cell = ct * 32 + r;
@@ -285,22 +332,11 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
                     v[i] = acc[ct][4 * q + i];
                 if constexpr (DT == AZH_DTYPE_F32) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int off = unit_off<DT>(cell, ch + i);
-                        if (skip)
-                            v[i] += *reinterpret_cast<const float *>(skip + off);
-                        *reinterpret_cast<float *>(out + off) = v[i] > 0.0f ? v[i] : 0.0f;
-                    }
+                    for (int i = 0; i < 4; i++)
+                        *reinterpret_cast<float *>(out + G::ch_off(cell, ch + i)) = v[i] > 0.0f ? v[i] : 0.0f;
                 } else {
-                    typedef typename Tr::quad quad;
                     typedef typename Tr::pair pair;
-                    const int off = unit_off<DT>(cell, ch >> 3) + ((ch & 7) << 1);
-                    if (skip) {
-                        const quad sk = *reinterpret_cast<const quad *>(skip + off);
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            v[i] += (float)sk[i];
-                    }
+                    const int off = G::ch_off(cell, ch);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                         v[i] = v[i] > 0.0f ? v[i] : 0.0f;
@@ -315,9 +351,10 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
             }
         }
     }
+    if constexpr (STAMP) st[2] = stamp_now();
 }
 
-template <int DT, int NB, int WPS>
+template <int DT, int NB, int WPS, bool STAMP = false>
 __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
 {
     typedef Traits<DT> Tr;
@@ -333,9 +370,15 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
 
     unsigned char *buf0 = smem;
     unsigned char *buf1 = smem + G::IMG;
-    float *vcell = reinterpret_cast<float *>(smem + G::STAGE_OFF);
+    float *vcell = reinterpret_cast<float *>(smem + G::VCELL_OFF);
+    // diagnostic stamps (STAMP builds only): 4 per layer {loop start, loop end, epilogue end, barrier passed}
+    unsigned long long *st = nullptr;
+    if constexpr (STAMP) {
+        st = A.stamps + ((size_t)blockIdx.x * OCT + wave) * 128;
+        st[0] = stamp_now();
+    }
 
-    // zero both images (zero row, pad channels of the input planes, unused boards)
+    // zero both images (zero slots, pad channels of the input planes, unused boards)
     for (int i = tid * 16; i < 2 * G::IMG; i += NTHREADS * 16)
         *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -351,17 +394,17 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
         const float f1 = (float)((mover >> sq) & 1ULL), f2 = (float)((opp >> sq) & 1ULL);
         const float f3 = (float)((A.blockers >> sq) & 1ULL);
         if constexpr (DT == AZH_DTYPE_F32) {
-            *reinterpret_cast<float *>(buf0 + unit_off<DT>(cell, 0)) = 1.0f;
-            *reinterpret_cast<float *>(buf0 + unit_off<DT>(cell, 1)) = f1;
-            *reinterpret_cast<float *>(buf0 + unit_off<DT>(cell, 2)) = f2;
-            *reinterpret_cast<float *>(buf0 + unit_off<DT>(cell, 3)) = f3;
+            *reinterpret_cast<float *>(buf0 + G::ch_off(cell, 0)) = 1.0f;
+            *reinterpret_cast<float *>(buf0 + G::ch_off(cell, 1)) = f1;
+            *reinterpret_cast<float *>(buf0 + G::ch_off(cell, 2)) = f2;
+            *reinterpret_cast<float *>(buf0 + G::ch_off(cell, 3)) = f3;
         } else {
             typename Tr::quad o;
             o[0] = (typename Tr::elem)1.0f;
             o[1] = (typename Tr::elem)f1;
             o[2] = (typename Tr::elem)f2;
             o[3] = (typename Tr::elem)f3;
-            *reinterpret_cast<typename Tr::quad *>(buf0 + unit_off<DT>(cell, 0)) = o;
+            *reinterpret_cast<typename Tr::quad *>(buf0 + G::ch_off(cell, 0)) = o;
         }
     }
 
@@ -394,16 +437,34 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
 #pragma unroll
     for (int i = 0; i < 4; i++)
         aring[i] = wp[(size_t)i * OCT * 64 + wave * 64 + lane];
-    conv_layer<DT, NB, G::KSTEPS_IN>(smem, 0, buf1, nullptr, wp, aring, A.shift, vmask, wave, lane);
+    f32x16 sh;       // batch-norm shift of the coming layer, fetched one layer ahead
+    {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(A.shift + 32 * wave + 8 * q + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                sh[4 * q + i] = t4[i];
+        }
+    }
+    if constexpr (STAMP) st[1] = stamp_now();
+    // (the shift table has one spare row so the last layer's look-ahead stays in bounds)
+    conv_layer<DT, NB, G::KSTEPS_IN, STAMP>(smem, 0, buf1, nullptr, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
     __syncthreads();
+    if constexpr (STAMP) st[7] = stamp_now();
     wp += l0;
     for (int b = 0; b < A.blocks; b++) {
         const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer<DT, NB, G::KSTEPS_FULL>(smem, G::IMG, buf0, nullptr, wp, aring, t1, vmask, wave, lane);
+        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP>(smem, G::IMG, buf0, nullptr, wp, aring, sh, t1 + F, vmask, wave, lane,
+                                                  st + 8 + 8 * b);
         __syncthreads();
+        if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
         wp += lf;
-        conv_layer<DT, NB, G::KSTEPS_FULL>(smem, 0, buf1, buf1, wp, aring, t1 + F, vmask, wave, lane);
+        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP>(smem, 0, buf1, buf1, wp, aring, sh, t1 + 2 * F, vmask, wave, lane,
+                                                  st + 12 + 8 * b);
         __syncthreads();
+        if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
         wp += lf;
     }
 
@@ -419,10 +480,10 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
             for (int i = 0; i < 16; i++)
                 acc[i] = 0.0f;
             const int cell = ct * 32 + r;
-            const int row = cell < G::NC ? cell : G::NC;
+            const int slot = cell < G::NC ? cell : G::zero_slot(cell);
             for (int ks = 0; ks < G::KSTEPS_FULL; ks++) {
                 const afrag a = hp[(size_t)ks * 64];
-                const afrag bfrag = *reinterpret_cast<const afrag *>(buf1 + unit_off<DT>(row, 2 * ks + h));
+                const afrag bfrag = *reinterpret_cast<const afrag *>(buf1 + G::off(slot, 2 * ks + h));
                 acc = Tr::mfma(a, bfrag, acc);
             }
             if (cell < G::NC) {
@@ -453,6 +514,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
             s = __builtin_fmaf(vcell[tid * 49 + c], A.fc_w[c], s);
         A.values[game] = tanhf(s + A.fc_b);
     }
+    if constexpr (STAMP) st[2] = stamp_now();
 }
 
 // ------------------------------------------------------------------ host side
@@ -583,7 +645,7 @@ extern "C" int azh_net_create(int blocks, int filters, const float *conv_flat, c
     const size_t n_conv = (size_t)9 * 4 * F + (size_t)2 * blocks * 9 * F * F + (size_t)F * 17 + F + 49 + 1;
     net->conv_flat.assign(conv_flat, conv_flat + n_conv);
     const int nbn = 2 * blocks + 1;
-    std::vector<float> scale((size_t)nbn * F), shift((size_t)nbn * F);
+    std::vector<float> scale((size_t)nbn * F), shift((size_t)(nbn + 1) * F, 0.0f);  // + one look-ahead row
     for (int l = 0; l < nbn; l++)
         for (int c = 0; c < F; c++) {
             const float mean = bn_flat[((size_t)2 * l) * F + c], var = bn_flat[((size_t)2 * l + 1) * F + c];
@@ -615,19 +677,20 @@ extern "C" void azh_net_destroy(azh_net *net)
     delete net;
 }
 
-template <int DT, int NB, int WPS> static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
+template <int DT, int NB, int WPS, bool STAMP = false>
+static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
 {
     typedef Geo<DT, NB> G;
     static bool attr_set = false;
     if (!attr_set) {
-        AZH_HIP(hipFuncSetAttribute((const void *)k_tower<DT, NB, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AZH_HIP(hipFuncSetAttribute((const void *)k_tower<DT, NB, WPS, STAMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     G::LDS_BYTES));
         attr_set = true;
     }
     const int grid = (max_n + G::BOARDS - 1) / G::BOARDS;
     if (grid <= 0)
         return 0;
-    hipLaunchKernelGGL((k_tower<DT, NB, WPS>), dim3(grid), dim3(NTHREADS), G::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL((k_tower<DT, NB, WPS, STAMP>), dim3(grid), dim3(NTHREADS), G::LDS_BYTES, stream, args);
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -648,7 +711,7 @@ static int tower_boards()
 // first n boards when both are null).  Everything is indexed by game.
 int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                    const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                   float *d_values, hipStream_t stream)
+                   float *d_values, hipStream_t stream, unsigned long long *d_stamps)
 {
     if (dtype < 0 || dtype > 2)
         return azh_fail(-2, "bad dtype %d", dtype);
@@ -668,7 +731,14 @@ int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, 
     a.blockers = blockers;
     a.logits = d_logits;
     a.values = d_values;
+    a.stamps = d_stamps;
     const bool six = tower_boards() == 6;
+    if (d_stamps) {  // diagnostic instantiations (bf16 only)
+        if (dtype != AZH_DTYPE_BF16)
+            return azh_fail(-2, "stamps are built for bf16 only");
+        return six ? launch_tower<AZH_DTYPE_BF16, 6, 1, true>(a, max_n, stream)
+                   : launch_tower<AZH_DTYPE_BF16, 3, 2, true>(a, max_n, stream);
+    }
     switch (dtype) {
     case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 3, 1>(a, max_n, stream);
     case AZH_DTYPE_BF16:
@@ -691,7 +761,7 @@ extern "C" int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *l
     AZH_HIP(hipMalloc((void **)&d_l, (size_t)n * 833 * 4));
     AZH_HIP(hipMalloc((void **)&d_v, (size_t)n * 4));
     AZH_HIP(hipMemcpy(d_b, leaf_boards, (size_t)n * 16, hipMemcpyHostToDevice));
-    int rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, blockers, d_l, d_v, 0);
+    int rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, blockers, d_l, d_v, 0, nullptr);
     if (rc == 0) {
         AZH_HIP(hipDeviceSynchronize());
         AZH_HIP(hipMemcpy(logits_out, d_l, (size_t)n * 833 * 4, hipMemcpyDeviceToHost));
@@ -731,10 +801,10 @@ extern "C" int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *m
     AZH_HIP(hipEventCreate(&e1));
     int rc = 0;
     for (int i = 0; i < 3 && rc == 0; i++)
-        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st);
+        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st, nullptr);
     AZH_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters && rc == 0; i++)
-        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st);
+        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st, nullptr);
     AZH_HIP(hipEventRecord(e1, st));
     AZH_HIP(hipStreamSynchronize(st));
     float ms = 0.0f;
@@ -746,5 +816,40 @@ extern "C" int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *m
     (void)hipFree(d_b);
     (void)hipFree(d_l);
     (void)hipFree(d_v);
+    return rc;
+}
+
+// Diagnostic: one launch of the stamped bf16 tower over n synthetic boards; copies the
+// s_memtime stamps of the first `wgs` workgroups ([wg][wave][128] u64) to `out`.
+extern "C" int azh_net_stamps(azh_net *net, int n, int wgs, uint64_t *out)
+{
+    if (!net || n <= 0 || wgs <= 0 || !out)
+        return azh_fail(-1, "azh_net_stamps: bad argument");
+    const int grid_max = (n + 2) / 3;
+    std::vector<unsigned long long> boards((size_t)n * 2);
+    unsigned long long x = 0x9E3779B97F4A7C15ULL;
+    for (int i = 0; i < n; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const unsigned long long m = x & 0x1FFFFFFFFFFFFULL;
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        boards[2 * (size_t)i] = m;
+        boards[2 * (size_t)i + 1] = x & 0x1FFFFFFFFFFFFULL & ~m;
+    }
+    unsigned long long *d_b = nullptr, *d_s = nullptr;
+    float *d_l = nullptr, *d_v = nullptr;
+    const size_t sbytes = (size_t)grid_max * OCT * 128 * 8;
+    AZH_HIP(hipMalloc((void **)&d_b, (size_t)n * 16));
+    AZH_HIP(hipMalloc((void **)&d_l, (size_t)n * 833 * 4));
+    AZH_HIP(hipMalloc((void **)&d_v, (size_t)n * 4));
+    AZH_HIP(hipMalloc((void **)&d_s, sbytes));
+    AZH_HIP(hipMemset(d_s, 0, sbytes));
+    AZH_HIP(hipMemcpy(d_b, boards.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    int rc = 0;
+    for (int i = 0; i < 3 && rc == 0; i++)
+        rc = azh_net_launch(net, AZH_DTYPE_BF16, d_b, nullptr, nullptr, n, 0, d_l, d_v, 0, d_s);
+    AZH_HIP(hipDeviceSynchronize());
+    const int have = wgs < grid_max ? wgs : grid_max;
+    AZH_HIP(hipMemcpy(out, d_s, (size_t)have * OCT * 128 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_b); (void)hipFree(d_l); (void)hipFree(d_v); (void)hipFree(d_s);
     return rc;
 }

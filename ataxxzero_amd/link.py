@@ -71,6 +71,7 @@ SIGNATURES = {
     "azh_net_destroy": (None, [_vp]),
     "azh_net_forward": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
     "azh_net_bench": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P(_f32)]),
+    "azh_net_stamps": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "azh_engine_create": (ctypes.c_int, [_P(Config), _P(_vp)]),
     "azh_engine_destroy": (None, [_vp]),
     "azh_engine_node_cap": (ctypes.c_int, [_vp]),
@@ -244,6 +245,11 @@ class Net:
         ms = ctypes.c_float(0)
         check(load().azh_net_bench(self.h, dtype, n, iters, ctypes.byref(ms)))
         return float(ms.value)
+
+    def stamps(self, n, wgs=64):
+        out = np.zeros((wgs, 4, 128), dtype=np.uint64)
+        check(load().azh_net_stamps(self.h, n, wgs, _ptr(out)))
+        return out
 
     def close(self):
         if getattr(self, "h", None):

@@ -103,6 +103,9 @@ int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards,
 /* Measurement hook: average HIP-event milliseconds per launch of the tower kernel over
  * n synthetic boards (iters launches on one stream, 3 untimed warm-up launches). */
 int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out);
+/* Diagnostic build of the bf16 tower with s_memtime stamps per layer phase: copies the
+ * stamps of the first `wgs` workgroups, [wg][wave][128] u64, to out (layout: net_kernels.hip). */
+int azh_net_stamps(azh_net *net, int n, int wgs, uint64_t *out);
 
 /* ------------------------------------------------------------------ engine
  * Replaces the worker threads of cpp/self_play_client.cpp: MCTS::step (:419-473),
