@@ -52,6 +52,13 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 constexpr int F = 128;        // filters (model.py:16)
 constexpr int OCT = F / 32;   // 32-channel output tiles = waves per workgroup
 constexpr int NTHREADS = 64 * OCT;
+#ifndef AZH_RING
+#define AZH_RING 4
+#endif
+constexpr int RING = AZH_RING;   // A-fragment look-ahead in k-steps (a power of two dividing 8)
+#ifndef AZH_BDIST
+#define AZH_BDIST 2
+#endif
 
 template <int DT> struct Traits;
 
@@ -155,7 +162,7 @@ __device__ inline unsigned long long stamp_now()
 template <int DT, int NB, int KS, bool STAMP = false>
 __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned char *out, const unsigned char *skip,
                                   const typename Traits<DT>::afrag *__restrict__ wp,
-                                  typename Traits<DT>::afrag (&a)[4], f32x16 &sh, const float *__restrict__ shift_next,
+                                  typename Traits<DT>::afrag (&a)[RING], f32x16 &sh, const float *__restrict__ shift_next,
                                   const int (&vmask)[Geo<DT, NB>::NT], int wave, int lane,
                                   unsigned long long *st = nullptr)
 {
@@ -243,43 +250,43 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
     };
 
     // Software pipeline.  Step s = (tap, ks): while its MFMAs run, the B fragments of step
-    // s+1 are on their way from LDS and the A fragment of step s+4 from L2.  The body is
+    // s+BD are on their way from LDS and the A fragment of step s+RING from L2.  The body is
     // straight-line code (compile-time phases, no branches) so that the waits the compiler
-    // inserts are exact counted waits and never drain the prefetch.
-    afrag b[2][NT];
+    // inserts are exact counted waits and never drain the prefetch.  BD = 2 for the 16-bit
+    // towers (a lone wave's step is only 160 cycles, less than a loaded LDS round trip).
+    constexpr int BD = (DT == AZH_DTYPE_F32) ? 1 : AZH_BDIST;
+    constexpr int NBUF = BD + 1;
+    afrag b[NBUF][NT];
     int cur[NT], nxt[NT];
-    auto one_step = [&](auto ph_tag, auto par_tag, const int (&src)[NT], int ks_next, int s) {
-        constexpr int ph = decltype(ph_tag)::value, par = decltype(par_tag)::value;
-        load_b(b[par ^ 1], src, ks_next);
-        __builtin_amdgcn_sched_barrier(0);  // next step's LDS reads stay ahead of this step's MFMAs
+    auto one_step = [&](auto ph_tag, auto buf_tag, const int (&src)[NT], int ks_target, int s) {
+        constexpr int ph = decltype(ph_tag)::value, bu = decltype(buf_tag)::value;
+        load_b(b[(bu + BD) % NBUF], src, ks_target);
+        __builtin_amdgcn_sched_barrier(0);  // the prefetch stays ahead of this step's MFMAs
 #pragma unroll
         for (int ct = 0; ct < NT; ct++)
-            acc[ct] = Tr::mfma(a[ph], b[par][ct], acc[ct]);
-        a[ph] = load_a(s + 4);
+            acc[ct] = Tr::mfma(a[ph], b[bu][ct], acc[ct]);
+        a[ph] = load_a(s + RING);
     };
-    rows_for(0, cur);
-    load_b(b[0], cur, 0);
     if constexpr (STAMP) st[0] = stamp_now();
 
     if constexpr (TOTAL <= 18) {
-        // few steps (the 4-plane input layer): everything unrolled
-        static_for<0, 9>([&](auto tap_tag) {
-            constexpr int tap = decltype(tap_tag)::value;
-            rows_for(tap < 8 ? tap + 1 : 8, nxt);
-            static_for<0, KS>([&](auto ks_tag) {
-                constexpr int ks = decltype(ks_tag)::value, s = tap * KS + ks;
-                if constexpr (ks + 1 < KS)
-                    one_step(IC<(s & 3)>(), IC<(s & 1)>(), cur, ks + 1, s);
-                else
-                    one_step(IC<(s & 3)>(), IC<(s & 1)>(), nxt, 0, s);
-            });
-#pragma unroll
-            for (int ct = 0; ct < NT; ct++)
-                cur[ct] = nxt[ct];
+        // few steps (the 4-plane input layer): everything unrolled, rows recomputed per step
+        static_for<0, BD>([&](auto i_tag) {
+            constexpr int i = decltype(i_tag)::value;
+            rows_for(i / KS, cur);
+            load_b(b[i % NBUF], cur, i % KS);
         });
-    } else {
-        static_assert(KS % 4 == 0, "k-steps per tap must be a multiple of the A ring");
-        constexpr int CH = KS <= 8 ? KS : 4;   // unrolled steps per chunk
+        static_for<0, TOTAL>([&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value, t = s + BD;
+            constexpr int tap_t = t / KS < 9 ? t / KS : 8;
+            rows_for(tap_t, cur);
+            one_step(IC<(s % RING)>(), IC<(s % NBUF)>(), cur, t % KS, s);
+        });
+    } else if constexpr (BD == 1) {
+        static_assert(KS % RING == 0, "k-steps per tap must be a multiple of the A ring");
+        constexpr int CH = KS <= 8 ? KS : RING;   // unrolled steps per chunk
+        rows_for(0, cur);
+        load_b(b[0], cur, 0);
         for (int tap = 0; tap < 9; tap++) {
             rows_for(tap < 8 ? tap + 1 : 8, nxt);
             for (int k0 = 0; k0 < KS; k0 += CH) {
@@ -293,28 +300,52 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
                 static_for<0, CH>([&](auto j_tag) {
                     constexpr int j = decltype(j_tag)::value;
                     if constexpr (j + 1 < CH)
-                        one_step(IC<(j & 3)>(), IC<(j & 1)>(), cur, k0 + j + 1, s0 + j);
+                        one_step(IC<(j % RING)>(), IC<(j & 1)>(), cur, k0 + j + 1, s0 + j);
                     else
-                        one_step(IC<(j & 3)>(), IC<(j & 1)>(), tail, tail_ks, s0 + j);
+                        one_step(IC<(j % RING)>(), IC<(j & 1)>(), tail, tail_ks, s0 + j);
                 });
             }
 #pragma unroll
             for (int ct = 0; ct < NT; ct++)
                 cur[ct] = nxt[ct];
         }
+    } else {
+        // KS steps per tap, B fragments two steps ahead in three buffers: the unrolled body
+        // covers three taps so that every buffer and ring slot keeps a compile-time name.
+        static_assert(BD == 2 && KS >= BD && (3 * KS) % RING == 0, "pipeline shape");
+        rows_for(0, cur);
+        load_b(b[0], cur, 0);
+        load_b(b[1], cur, 1);
+        for (int t0 = 0; t0 < 9; t0 += 3) {
+            static_for<0, 3>([&](auto tt_tag) {
+                constexpr int tt = decltype(tt_tag)::value;
+                const int tap = t0 + tt;
+                rows_for(tap < 8 ? tap + 1 : 8, nxt);
+                static_for<0, KS>([&](auto j_tag) {
+                    constexpr int j = decltype(j_tag)::value, sl = tt * KS + j;
+                    if constexpr (j + BD < KS)
+                        one_step(IC<(sl % RING)>(), IC<(sl % NBUF)>(), cur, j + BD, tap * KS + j);
+                    else
+                        one_step(IC<(sl % RING)>(), IC<(sl % NBUF)>(), nxt, j + BD - KS, tap * KS + j);
+                });
+#pragma unroll
+                for (int ct = 0; ct < NT; ct++)
+                    cur[ct] = nxt[ct];
+            });
+        }
     }
 
     if constexpr (STAMP) st[1] = stamp_now();
     fetch_shift();  // next layer's shift: in flight behind the epilogue and the barrier
-    // the ring now holds steps TOTAL .. TOTAL+3 at slots (TOTAL + i) % 4: rotate so that
-    // slot i is the next layer's step i
-    if constexpr (TOTAL % 4 != 0) {
-        afrag t[4];
+    // the ring now holds steps TOTAL .. TOTAL+RING-1 at slots (TOTAL + i) % RING: rotate so
+    // that slot i is the next layer's step i
+    if constexpr (TOTAL % RING != 0) {
+        afrag t[RING];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            t[i] = a[(TOTAL + i) % 4];
+        for (int i = 0; i < RING; i++)
+            t[i] = a[(TOTAL + i) % RING];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < RING; i++)
             a[i] = t[i];
     }
 
@@ -433,9 +464,9 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w);
     const size_t l0 = (size_t)9 * G::KSTEPS_IN * OCT * 64;
     const size_t lf = (size_t)9 * G::KSTEPS_FULL * OCT * 64;
-    afrag aring[4];  // A-fragment ring, kept warm across layers
+    afrag aring[RING];  // A-fragment ring, kept warm across layers
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < RING; i++)
         aring[i] = wp[(size_t)i * OCT * 64 + wave * 64 + lane];
     f32x16 sh;       // batch-norm shift of the coming layer, fetched one layer ahead
     {
@@ -609,7 +640,7 @@ static int net_pack(azh_net *net, int dt)
         for (int l = 0; l < 2 * B; l++)
             pack_conv<float>(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, sc + (size_t)(l + 1) * F, F, 9, ks_full, kstep,
                              OCT, F, dt, cw);
-        cw.resize(cw.size() + 4 * OCT * 64, 0.0f);  // the A ring reads four steps past the last layer
+        cw.resize(cw.size() + (size_t)RING * OCT * 64, 0.0f);  // the A ring reads RING steps past the last layer
         pack_conv<float>(head.data(), nullptr, F, 1, ks_full, kstep, 1, 32, dt, hw);
         if (upload(cw.data(), cw.size() * 4, &net->bufs[dt].conv_w)) return -1;
         if (upload(hw.data(), hw.size() * 4, &net->bufs[dt].head_w)) return -1;
@@ -620,7 +651,7 @@ static int net_pack(azh_net *net, int dt)
         for (int l = 0; l < 2 * B; l++)
             pack_conv<uint16_t>(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, sc + (size_t)(l + 1) * F, F, 9, ks_full,
                                 kstep, OCT, F, dt, cw);
-        cw.resize(cw.size() + 4 * OCT * 64 * 8, 0);  // the A ring reads four steps past the last layer
+        cw.resize(cw.size() + (size_t)RING * OCT * 64 * 8, 0);  // the A ring reads RING steps past the last layer
         pack_conv<uint16_t>(head.data(), nullptr, F, 1, ks_full, kstep, 1, 32, dt, hw);
         if (upload(cw.data(), cw.size() * 2, &net->bufs[dt].conv_w)) return -1;
         if (upload(hw.data(), hw.size() * 2, &net->bufs[dt].head_w)) return -1;
