@@ -130,53 +130,92 @@ __host__ __device__ inline int policy_index(u32 move)
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Cross-lane traffic goes through DPP (VALU speed), not ds_bpermute (an LDS round trip per
+// hop): the PUCT descent is a dependent chain of ~15 reductions per tree level.
+// gfx9 DPP controls: quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_mirror 0x140,
+// row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ inline int dpp_i32(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ inline int bcast_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
+// value of lane `src`, where src is the same in every lane (a scalar): v_readlane, no LDS hop
+__device__ inline int read_lane(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+
+// Inclusive prefix sum over the 64 lanes.
 __device__ inline int wave_incl_scan(int v)
 {
-    int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(v, off, 64);
-        if (lane >= off)
-            v += t;
-    }
+    v += dpp_i32<0x111>(0, v);          // row_shr:1 (lanes without a source add 0)
+    v += dpp_i32<0x112>(0, v);          // row_shr:2
+    v += dpp_i32<0x114>(0, v);          // row_shr:4
+    v += dpp_i32<0x118>(0, v);          // row_shr:8  -> inclusive within each row of 16
+    v += dpp_i32<0x142, 0xA>(0, v);     // row_bcast15 into rows 1 and 3
+    v += dpp_i32<0x143, 0xC>(0, v);     // row_bcast31 into rows 2 and 3
     return v;
 }
 
+// Reductions leave the result in lane 63 and broadcast it through a scalar register.
 __device__ inline int wave_sum_int(int v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-        v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_i32<0xB1>(0, v);           // quad_perm [1,0,3,2]
+    v += dpp_i32<0x4E>(0, v);           // quad_perm [2,3,0,1]
+    v += dpp_i32<0x141>(0, v);          // row_half_mirror
+    v += dpp_i32<0x140>(0, v);          // row_mirror
+    v += dpp_i32<0x142, 0xA>(0, v);
+    v += dpp_i32<0x143, 0xC>(0, v);
+    return bcast_last(v);
 }
 
-__device__ inline u32 wave_sum_u32(u32 v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-        v += (u32)__shfl_xor((int)v, off, 64);
-    return v;
-}
+__device__ inline u32 wave_sum_u32(u32 v) { return (u32)wave_sum_int((int)v); }
 
-// xor-butterfly f32 sum: every lane ends with the same bits (IEEE add commutes).
+// f32 sum in the canonical order of the engine/oracle contract: the xor butterfly with
+// offsets 1, 2, 4, 8, 16, 32 (pairs, quads, ... halves); lane 63 carries exactly that
+// value (every add below pairs the two operands the butterfly pairs).
 __device__ inline float wave_sum_f32(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float t = __shfl_xor(v, off, 64);
-        v = v + t;
-    }
-    return v;
+    v = v + __int_as_float(dpp_i32<0xB1>(0, __float_as_int(v)));
+    v = v + __int_as_float(dpp_i32<0x4E>(0, __float_as_int(v)));
+    v = v + __int_as_float(dpp_i32<0x141>(0, __float_as_int(v)));
+    v = v + __int_as_float(dpp_i32<0x140>(0, __float_as_int(v)));
+    v = v + __int_as_float(dpp_i32<0x142, 0xA>(0, __float_as_int(v)));
+    v = v + __int_as_float(dpp_i32<0x143, 0xC>(0, __float_as_int(v)));
+    return __int_as_float(bcast_last(__float_as_int(v)));
 }
 
 __device__ inline float wave_max_f32(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float t = __shfl_xor(v, off, 64);
-        v = t > v ? t : v;
-    }
-    return v;
+    const auto mx = [](float a, float b) { return b > a ? b : a; };
+    v = mx(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v), __float_as_int(v))));
+    v = mx(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v), __float_as_int(v))));
+    v = mx(v, __int_as_float(dpp_i32<0x141>(__float_as_int(v), __float_as_int(v))));
+    v = mx(v, __int_as_float(dpp_i32<0x140>(__float_as_int(v), __float_as_int(v))));
+    v = mx(v, __int_as_float(dpp_i32<0x142, 0xA>(__float_as_int(v), __float_as_int(v))));
+    v = mx(v, __int_as_float(dpp_i32<0x143, 0xC>(__float_as_int(v), __float_as_int(v))));
+    return __int_as_float(bcast_last(__float_as_int(v)));
+}
+
+// max of a 64-bit key (used for arg-max as (score bits << 32) | index)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ inline u64 dpp_max_u64(u64 v)
+{
+    const u32 lo = (u32)dpp_i32<CTRL, ROW_MASK>((int)(u32)v, (int)(u32)v);
+    const u32 hi = (u32)dpp_i32<CTRL, ROW_MASK>((int)(u32)(v >> 32), (int)(u32)(v >> 32));
+    const u64 o = ((u64)hi << 32) | lo;
+    return o > v ? o : v;
+}
+
+__device__ inline u64 wave_max_u64(u64 v)
+{
+    v = dpp_max_u64<0xB1>(v);
+    v = dpp_max_u64<0x4E>(v);
+    v = dpp_max_u64<0x141>(v);
+    v = dpp_max_u64<0x140>(v);
+    v = dpp_max_u64<0x142, 0xA>(v);
+    v = dpp_max_u64<0x143, 0xC>(v);
+    const u32 lo = (u32)bcast_last((int)(u32)v), hi = (u32)bcast_last((int)(u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
 }
 
 // ---------------------------------------------------------------- wave movegen
@@ -197,7 +236,7 @@ __device__ inline int wave_movegen(const Board &b, u64 blockers, u16 *moves, int
         targets = double_jump_bb(1ULL << lane) & empty;
     int cnt = __popcll(targets);
     int incl = wave_incl_scan(cnt);
-    int jumps = __shfl(incl, 63, 64);
+    int jumps = bcast_last(incl);
     u64 clones = single_jump_bb(own) & empty;
     int n_clones = __popcll(clones);
     int total = jumps + n_clones;

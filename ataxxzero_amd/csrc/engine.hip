@@ -18,6 +18,8 @@
 //   node_info  [2][G][node_cap]  16 B  first_edge, n_edges | result<<16, -, terminal value
 //   edge       [2][G][edge_cap]  16 B  prior f32, visits u32, total score f32, child u32
 //   edge_move  [2][G][edge_cap]   2 B  from | to<<8
+//   edge_kid   [2][G][edge_cap]   8 B  the child's (first_edge, n_edges | result<<16): derived
+//                                       copy of its node_info, so a PUCT level is ONE memory round trip
 // A node's children are one contiguous edge range, so PUCT reads them with a
 // single coalesced 16-byte-per-lane load; children are bump-allocated by the one
 // wave that owns the game (no atomics inside a tree).
@@ -51,6 +53,7 @@ struct EngineParams {
     uint4 *node_info;
     uint4 *edge;
     u16 *edge_move;
+    uint2 *edge_kid;
     ulonglong2 *leaf_board;
     int *need_eval;
     int *leaf_list;
@@ -69,6 +72,7 @@ struct Arena {
     uint4 *ni;
     uint4 *ed;
     u16 *em;
+    uint2 *ek;
 };
 
 __device__ inline Arena arena_of(const EngineParams &P, int a, int g)
@@ -79,6 +83,7 @@ __device__ inline Arena arena_of(const EngineParams &P, int a, int g)
     A.ni = P.node_info + slot * P.node_cap;
     A.ed = P.edge + slot * P.edge_cap;
     A.em = P.edge_move + slot * P.edge_cap;
+    A.ek = P.edge_kid + slot * P.edge_cap;
     return A;
 }
 
@@ -104,6 +109,7 @@ __device__ inline void init_game(const EngineParams &P, int g, u32 uid, azh_game
     for (int j = lane; j < M; j += WAVE) {
         A.ed[j] = make_uint4(0u, 0u, 0u, NONE);
         A.em[j] = s_moves[j];
+        A.ek[j] = make_uint2(0u, 0u);
     }
     if (lane == 0) {
         A.nb[0] = make_ulonglong2(pack_word0(b), b.o);
@@ -160,11 +166,11 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
     } else {
         st_steps = 1;
         u32 node = 0;
+        const uint4 rinfo = A.ni[0];
+        u32 first = rinfo.x, ninfo = rinfo.y;  // edge range + result of the node being scanned
         for (;;) {
-            const uint4 info = A.ni[node];
-            const u32 first = info.x;
-            const int M = (int)(info.y & 0xFFFFu);
-            const int result = (int)(info.y >> 16);
+            const int M = (int)(ninfo & 0xFFFFu);
+            const int result = (int)(ninfo >> 16);
             if (result != 0 || M == 0) {
                 kind = AZH_LEAF_TERMINAL;  // select_action -> NO_MOVE (:336-340)
                 leaf_node = (int)node;
@@ -174,20 +180,25 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
             st_children += (u64)M;
             const int rounds = (M + 63) >> 6;
             uint4 ev[4];
+            uint2 kv[4];
             u32 nsum = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 ev[k] = make_uint4(0u, 0u, 0u, NONE);
+                kv[k] = make_uint2(0u, 0u);
                 const int j = lane + 64 * k;
                 if (k < rounds && j < M) {
                     ev[k] = A.ed[first + j];
+                    kv[k] = A.ek[first + j];  // independent load: same round trip as the edge
                     nsum += ev[k].y;
                 }
             }
             const u32 ntot = wave_sum_u32(nsum);
             const float sq = sqrtf((float)(1u + ntot));
-            float best = -INFINITY;
-            int bj = -1;
+            // arg-max with ties to the LAST maximal edge (:354): scores are >= 0, so their bit
+            // patterns order like the floats and (bits << 32 | index) is a total order; NaN
+            // scores (never selected by the reference's `>=`) and empty lanes map to key 0.
+            u64 key = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int j = lane + 64 * k;
@@ -198,32 +209,24 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
                     const float q = n ? W / (float)n : 0.0f;
                     const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
                     const float score = u + q;
-                    if (score > best || (score == best && j > bj)) {
-                        best = score;
-                        bj = j;
-                    }
+                    const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)(u32)j : 0ull;
+                    key = kj > key ? kj : key;
                 }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ob = __shfl_xor(best, off, 64);
-                const int oj = __shfl_xor(bj, off, 64);
-                if (ob > best || (ob == best && oj > bj)) {
-                    best = ob;
-                    bj = oj;
-                }
-            }
-            if (bj < 0)
-                bj = 0;
+            key = wave_max_u64(key);
+            const int bj = (int)(u32)key;
             const u32 eidx = first + (u32)bj;
             if (lane == 0)
                 path[depth] = (int)eidx;
             depth++;
             const int kk = bj >> 6;
             const u32 mine = kk == 0 ? ev[0].w : (kk == 1 ? ev[1].w : (kk == 2 ? ev[2].w : ev[3].w));
-            const u32 child = (u32)__shfl((int)mine, bj & 63, 64);
+            const uint2 mkid = kk == 0 ? kv[0] : (kk == 1 ? kv[1] : (kk == 2 ? kv[2] : kv[3]));
+            const u32 child = (u32)read_lane((int)mine, bj & 63);
             if (child != NONE) {
                 node = child;
+                first = (u32)read_lane((int)mkid.x, bj & 63);
+                ninfo = (u32)read_lane((int)mkid.y, bj & 63);
                 continue;
             }
             // expand (:429-439)
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
                 for (int j = lane; j < M2; j += WAVE) {
                     A.ed[nf + j] = make_uint4(0u, 0u, 0u, NONE);
                     A.em[nf + j] = s_moves[j];
+                    A.ek[nf + j] = make_uint2(0u, 0u);
                 }
                 s.n_edges += M2;
                 if (lane == 0)
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
             if (lane == 0) {
                 A.nb[cid] = make_ulonglong2(pack_word0(cb), cb.o);
                 reinterpret_cast<u32 *>(&A.ed[eidx])[3] = cid;
+                A.ek[eidx] = res2 != 0 ? make_uint2(0u, (u32)res2 << 16) : make_uint2((u32)(s.n_edges - M2), (u32)M2);
             }
             leaf_node = (int)cid;
             leaf_mover = cb.turn ? cb.o : cb.x;
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(WAVE) void k_backup(EngineParams P)
 __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
 {
     __shared__ u16 s_moves[MAX_MOVES];
+    __shared__ u32 s_old[WAVE], s_pref[WAVE + 1];
     const int g = blockIdx.x, lane = threadIdx.x;
     azh_game_state s = P.gs[g];
     // while (root.all_edge_visits < global_visits) step();  (:522-525)
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
         const u64 mask = __ballot(j < M && cum > r);
         if (chosen < 0 && mask)
             chosen = 64 * k + (__ffsll((long long)mask) - 1);
-        run += (u32)__shfl(incl, 63, 64);
+        run += (u32)bcast_last(incl);
     }
     if (chosen < 0)
         chosen = 0;
@@ -484,8 +490,8 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
     const int ck = chosen >> 6, cl = chosen & 63;
     const u32 my_mv = ck == 0 ? mvs[0] : (ck == 1 ? mvs[1] : (ck == 2 ? mvs[2] : mvs[3]));
     const u32 my_ch = ck == 0 ? ev[0].w : (ck == 1 ? ev[1].w : (ck == 2 ? ev[2].w : ev[3].w));
-    const u32 mv = (u32)__shfl((int)my_mv, cl, 64);
-    const u32 c = (u32)__shfl((int)my_ch, cl, 64);
+    const u32 mv = (u32)read_lane((int)my_mv, cl);
+    const u32 c = (u32)read_lane((int)my_ch, cl);
     const ulonglong2 rootw = A.nb[0];
     if (lane == 0) {
         const u64 bx = rootw.x & ~TURN_BIT;
@@ -512,6 +518,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
         for (int j = lane; j < Mw; j += WAVE) {
             B.ed[j] = make_uint4(0u, 0u, 0u, NONE);
             B.em[j] = s_moves[j];
+            B.ek[j] = make_uint2(0u, 0u);
         }
         if (lane == 0) {
             float tv = result == 1 ? 1.0f : -1.0f;
@@ -531,38 +538,72 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
             B.ni[0] = cinfo;
         }
         __syncthreads();
-        u32 t = 1, eb = 0, rv = 0;
-        for (u32 q = 0; q < t; q++) {
-            const uint4 qi = B.ni[q];
-            const u32 of = qi.x, Mq = qi.y & 0xFFFFu, nf = eb;
-            eb += Mq;
-            for (u32 j0 = 0; j0 < Mq; j0 += WAVE) {
-                const u32 j = j0 + (u32)lane;
-                const bool valid = j < Mq;
-                uint4 e = make_uint4(0u, 0u, 0u, NONE);
+        // Breadth-first copy, up to 64 frontier nodes per pass.  Nodes are numbered in
+        // (parent order, edge order) and a node's edges land at the running edge count,
+        // exactly as the node-at-a-time loop of the oracle does, so the compacted arena is
+        // bit-identical — only the dependent-load chain is per pass instead of per node.
+        int *parent_edge = P.path + (size_t)g * P.path_cap;  // free between backup and select
+        u32 t = 1, eb = 0, rv = 0, qs = 0;
+        while (qs < t) {
+            const u32 nchunk = min(t - qs, (u32)WAVE);
+            u32 of = 0, Mq = 0, qy = 0;
+            if ((u32)lane < nchunk) {
+                const uint4 qi = B.ni[qs + lane];
+                of = qi.x;
+                Mq = qi.y & 0xFFFFu;
+                qy = qi.y;
+            }
+            const u32 incl = (u32)wave_incl_scan((int)Mq);
+            const u32 Ef = (u32)bcast_last((int)incl);
+            if ((u32)lane < nchunk) {
+                const u32 nf = Mq ? eb + incl - Mq : 0u;
+                s_old[lane] = of;
+                s_pref[lane] = incl - Mq;
+                reinterpret_cast<u32 *>(&B.ni[qs + lane])[0] = nf;
+                if (qs + lane > 0)
+                    B.ek[parent_edge[qs + lane]] = make_uint2(nf, qy);
+            }
+            if (lane == 0)
+                s_pref[nchunk] = Ef;
+            __syncthreads();
+            for (u32 e0 = 0; e0 < Ef; e0 += WAVE) {
+                const u32 e = e0 + (u32)lane;
+                const bool valid = e < Ef;
+                uint4 ed = make_uint4(0u, 0u, 0u, NONE);
                 u16 m = 0;
                 if (valid) {
-                    e = A.ed[of + j];
-                    m = A.em[of + j];
+                    u32 lo = 0, hi = nchunk;  // largest i with s_pref[i] <= e
+                    while (hi - lo > 1) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= e) lo = mid;
+                        else hi = mid;
+                    }
+                    const u32 src = s_old[lo] + (e - s_pref[lo]);
+                    ed = A.ed[src];
+                    m = A.em[src];
+                    if (qs == 0 && lo == 0)
+                        rv += ed.y;
                 }
-                const bool has = valid && e.w != NONE;
+                const bool has = valid && ed.w != NONE;
                 const u64 mask = __ballot(has);
+                const u32 dst = eb + e;
                 if (has) {
                     const u32 nc = t + (u32)__popcll(mask & lt);
-                    B.nb[nc] = A.nb[e.w];
-                    B.ni[nc] = A.ni[e.w];
-                    e.w = nc;
+                    B.nb[nc] = A.nb[ed.w];
+                    B.ni[nc] = A.ni[ed.w];
+                    parent_edge[nc] = (int)dst;
+                    ed.w = nc;
                 }
                 if (valid) {
-                    B.ed[nf + j] = e;
-                    B.em[nf + j] = m;
-                    if (q == 0)
-                        rv += e.y;
+                    B.ed[dst] = ed;
+                    B.em[dst] = m;
+                    if (!has)
+                        B.ek[dst] = make_uint2(0u, 0u);
                 }
                 t += (u32)__popcll(mask);
             }
-            if (lane == 0)
-                reinterpret_cast<u32 *>(&B.ni[q])[0] = Mq ? nf : 0u;
+            eb += Ef;
+            qs += nchunk;
             __syncthreads();
         }
         s.n_nodes = (int)t;
@@ -586,7 +627,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
         u64 off = 0;
         if (lane == 0)
             off = atomicAdd((unsigned long long *)P.ring_head, (unsigned long long)words);
-        off = ((u64)(u32)__shfl((int)(off >> 32), 0, 64) << 32) | (u64)(u32)__shfl((int)off, 0, 64);
+        off = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)off);
         if (off + (u64)words <= P.ring_cap_words) {
             u32 *out = P.ring + off;
             if (lane == 0) {
@@ -746,6 +787,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.node_info, 2 * G * P.node_cap);
     rc |= dev_alloc(e, &P.edge, 2 * G * P.edge_cap);
     rc |= dev_alloc(e, &P.edge_move, 2 * G * P.edge_cap);
+    rc |= dev_alloc(e, &P.edge_kid, 2 * G * P.edge_cap);
     rc |= dev_alloc(e, &P.leaf_board, G);
     rc |= dev_alloc(e, &P.need_eval, G);
     rc |= dev_alloc(e, &P.leaf_list, G);

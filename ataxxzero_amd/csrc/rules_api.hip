@@ -89,7 +89,7 @@ __global__ void k_perft_level(const ulonglong2 *cur, u64 n, u64 blockers, ulongl
     const int children = i < n ? (cnt ? cnt : 1) : 0;
     // wave-aggregated reservation: one atomic per wave
     const int incl = wave_incl_scan(children);
-    const int total = __shfl(incl, 63, 64);
+    const int total = bcast_last(incl);
     if (leaf) {
         if (lane_id() == 63 && total)
             atomicAdd(leaf_total, (unsigned long long)total);

@@ -64,7 +64,8 @@ static void pack(const orc_pos *p, uint64_t *b)
     b[1] = p->pieces[1];
 }
 
-/* 64-lane emulation: sum v[0..n) as lane-striped partials + xor butterfly. */
+/* 64-lane emulation: sum v[0..n) as lane-striped partials + xor butterfly with offsets
+ * 1, 2, 4, 8, 16, 32 (the order the HIP engine's DPP reduction produces). */
 static float wave_sum(const float *v, int n)
 {
     float lane[64];
@@ -74,7 +75,7 @@ static float wave_sum(const float *v, int n)
             p = p + v[j];
         lane[l] = p;
     }
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 1; off <= 32; off <<= 1) {
         float t[64];
         for (int l = 0; l < 64; l++)
             t[l] = lane[l] + lane[l ^ off];
