@@ -1,0 +1,102 @@
+"""Batched head-to-head match between two nets on one GPU (BASELINE config 5).
+
+Restates what uai_ringmaster.py does with two `uai_interface.py --network-path X --visits V`
+engine subprocesses (uai_ringmaster.py:75-160,198-265), as one device-resident batch:
+  * no-blocker start (ataxx_rules.py:44-50), engine 1 ("white") moves first
+  * each side searches exactly `visits` MCTS steps per move from a fresh tree (the
+    per-ply `moves` message makes engine.set_state rebuild it, engine.py:452-472), no
+    Dirichlet noise, python posterior and tie-break (engine.py:197-203,291)
+  * the move is sampled ~ (n/N)^5 over edges with n >= max/2 (engine.py:532-548)
+  * a single legal move is played without search (uai_ringmaster.py:114-116)
+  * every pairing is played both ways (uai_ringmaster.py:241-247): even game slots give x to
+    net A, odd slots to net B
+  * result 1/2 scores a win for that colour's engine; a game cut at --max-plies is
+    "invalid": half a point each and counted as annulled (uai_ringmaster.py:251-257)
+"""
+import datetime
+import json
+
+from . import link, model, selfplay
+
+
+class Match:
+    def __init__(self, weights_a, weights_b, visits, games=1024, dtype="bf16", seed=selfplay.DEFAULT_SEED,
+                 max_plies=400):
+        if games % 2:
+            raise ValueError("the number of concurrent games must be even (each pairing is played both ways)")
+        self.net_a = link.Net(*weights_a, model.BN_EPSILON)
+        self.net_b = link.Net(*weights_b, model.BN_EPSILON)
+        self.dtype = link.DTYPES[dtype]
+        cfg = selfplay.make_config(games, visits, seed=seed, fen=selfplay.START_FEN_PLAIN, max_plies=max_plies,
+                                   dirichlet_weight=0.0, flags=link.FLAG_ARENA)
+        self.engine = link.Engine(cfg)
+        self.games = games
+
+    def run(self, iterations):
+        self.engine.run_arena(self.net_a, self.net_b, iterations, self.dtype)
+
+    def drain(self):
+        """Finished games: dicts with moves (UAI strings), result (1, 2 or 0 = cut), white ('a'/'b'),
+        final_score (x stones, o stones)."""
+        out = []
+        for line in self.engine.drain_json():
+            e = json.loads(line)
+            white = "a" if e["slot"] % 2 == 0 else "b"
+            out.append({"moves": e["moves"], "result": e["result"], "white": white, "uid": e["uid"],
+                        "final_score": replay_final_score(e), "boards": e["boards"]})
+        return out
+
+    def close(self):
+        self.engine.close()
+        self.net_a.close()
+        self.net_b.close()
+
+
+def replay_final_score(entry):
+    """Stone counts after the last move: boards[] holds the position BEFORE each move, so the last
+    move is applied to the last board (clone/jump + capture of the 8 neighbours)."""
+    if not entry["boards"]:
+        return (2, 2)
+    cells = list(entry["boards"][-1])
+    mv = entry["moves"][-1]
+    mover = 1 if (len(entry["moves"]) - 1) % 2 == 0 else 2
+
+    def sq(s):
+        return (ord(s[0]) - 97, 7 - int(s[1]))
+
+    if len(mv) == 4:
+        fx, fy = sq(mv[:2])
+        cells[fx + 7 * fy] = 0
+        tx, ty = sq(mv[2:])
+    else:
+        tx, ty = sq(mv)
+    cells[tx + 7 * ty] = mover
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            x, y = tx + dx, ty + dy
+            if 0 <= x < 7 and 0 <= y < 7 and cells[x + 7 * y] not in (0, mover):
+                cells[x + 7 * y] = mover
+    return (cells.count(1), cells.count(2))
+
+
+def write_game_to_pgn(path, game, white_name, black_name, round_index, tc):
+    """uai_ringmaster.write_game_to_pgn (:162-180), same tags and layout."""
+    now = datetime.datetime.now()
+    with open(path, "a+") as f:
+        print('[Event "?"]', file=f)
+        print('[Site "?"]', file=f)
+        print('[Date "%s"]' % (now.strftime("%Y.%m.%d"),), file=f)
+        print('[Round "%i"]' % (round_index,), file=f)
+        print('[White "%s"]' % (white_name,), file=f)
+        print('[Black "%s"]' % (black_name,), file=f)
+        print('[Opening "%s"]' % ("",), file=f)
+        print('[GameStartTime "%s"]' % (now.isoformat(),), file=f)
+        print('[GameEndTime "%s"]' % (now.isoformat(),), file=f)
+        print('[Plycount "%i"]' % (len(game["moves"]),), file=f)
+        result_string = {1: "1-0", 2: "0-1", 0: "1/2-1/2"}[game["result"]]
+        print('[Result "%s"]' % (result_string,), file=f)
+        print('[FinalScore "%i-%i"]' % tuple(game["final_score"]), file=f)
+        print('[TimeControl "+%r"]' % (tc,), file=f)
+        print(file=f)
+        print(" ".join(game["moves"]), file=f)
+        print(file=f)

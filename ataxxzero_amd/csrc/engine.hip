@@ -46,6 +46,7 @@ struct EngineParams {
     u32 k0, k1;
     u64 start_x, start_o, blockers;
     int start_turn;
+    u32 flags;
     azh_game_state *gs;
     int *force;
     int *path;
@@ -58,6 +59,8 @@ struct EngineParams {
     int *need_eval;
     int *leaf_list;
     int *leaf_count;
+    int *leaf_list2;   // arena: leaves of the games whose mover is net B
+    int *leaf_count2;
     float *logits;
     float *values;
     u32 *rec;
@@ -155,7 +158,12 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
     u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0;
     u64 leaf_mover = 0, leaf_opp = 0;
 
-    if (s.phase == 0) {
+    if (s.phase == 0 && (P.flags & AZH_FLAG_TWO_NETS) && (A.ni[0].y & 0xFFFFu) == 1u) {
+        // arena: a single legal move is played without search (uai_ringmaster.py:114-116)
+        kind = AZH_LEAF_NONE;
+        s.phase = 1;
+        over = 2;  // sets the force flag without counting an overflow
+    } else if (s.phase == 0) {
         // the root's priors are (re)computed with noise (:380-383, :485-490)
         kind = AZH_LEAF_ROOT;
         st_evals = 1;
@@ -195,9 +203,11 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
             }
             const u32 ntot = wave_sum_u32(nsum);
             const float sq = sqrtf((float)(1u + ntot));
-            // arg-max with ties to the LAST maximal edge (:354): scores are >= 0, so their bit
-            // patterns order like the floats and (bits << 32 | index) is a total order; NaN
-            // scores (never selected by the reference's `>=`) and empty lanes map to key 0.
+            // arg-max with ties to the LAST maximal edge (:354) — or the FIRST, python's max()
+            // (engine.py:291), in the arena: scores are >= 0, so their bit patterns order like
+            // the floats and (bits << 32 | index or ~index) is a total order; NaN scores (never
+            // selected by either reference) and empty lanes map to key 0.
+            const u32 tie_flip = (P.flags & AZH_FLAG_TIE_FIRST) ? 0xFFFFFFFFu : 0u;
             u64 key = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -209,12 +219,12 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
                     const float q = n ? W / (float)n : 0.0f;
                     const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
                     const float score = u + q;
-                    const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)(u32)j : 0ull;
+                    const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)((u32)j ^ tie_flip) : 0ull;
                     key = kj > key ? kj : key;
                 }
             }
             key = wave_max_u64(key);
-            const int bj = (int)(u32)key;
+            const int bj = key ? (int)((u32)key ^ tie_flip) : 0;
             const u32 eidx = first + (u32)bj;
             if (lane == 0)
                 path[depth] = (int)eidx;
@@ -283,7 +293,10 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
         s.leaf_node = leaf_node;
         s.path_len = depth;
         P.gs[g] = s;
-        P.need_eval[g] = (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) ? 1 : 0;
+        int need = (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) ? 1 : 0;
+        if (need && (P.flags & AZH_FLAG_TWO_NETS))
+            need = 1 + ((s.ply + g) & 1);  // net A (1) / net B (2) is to move; even slots give x to A
+        P.need_eval[g] = need;
         P.leaf_board[g] = make_ulonglong2(leaf_mover, leaf_opp);
         if (over)
             P.force[g] = 1;
@@ -292,12 +305,12 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
         add_stat(P, g, AZH_STAT_LEVELS, st_levels);
         add_stat(P, g, AZH_STAT_CHILDREN, st_children);
         add_stat(P, g, AZH_STAT_NEW_MOVES, st_newmoves);
-        add_stat(P, g, AZH_STAT_EDGE_OVERFLOW, (u64)over);
+        add_stat(P, g, AZH_STAT_EDGE_OVERFLOW, (u64)(over == 1));
     }
 }
 
 // Dense, game-ordered list of the games whose leaf needs the evaluator.
-__global__ __launch_bounds__(1024) void k_compact(const int *need, int G, int *list, int *count)
+__global__ __launch_bounds__(1024) void k_compact(const int *need, int G, int *list, int *count, int cls, int any)
 {
     __shared__ int s_sum[1024];
     const int t = threadIdx.x;
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_compact(const int *need, int G, int *l
     const int lo = t * c, hi = min(G, lo + c);
     int cnt = 0;
     for (int i = lo; i < hi; i++)
-        cnt += need[i] != 0;
+        cnt += any ? need[i] != 0 : need[i] == cls;
     s_sum[t] = cnt;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_compact(const int *need, int G, int *l
     }
     int base = s_sum[t] - cnt;
     for (int i = lo; i < hi; i++)
-        if (need[i])
+        if (any ? need[i] != 0 : need[i] == cls)
             list[base++] = i;
     if (t == 1023)
         *count = s_sum[1023];
@@ -343,33 +356,68 @@ __global__ __launch_bounds__(WAVE) void k_backup(EngineParams P)
         const int rounds = (M + 63) >> 6;
         const float *row = P.logits + (size_t)g * AZH_POLICY_SIZE;
         float l[4], ex[4];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = lane + 64 * k;
-            l[k] = -INFINITY;
-            if (k < rounds && j < M) {
-                l[k] = row[policy_index(A.em[first + j])];
-                if (l[k] > mx)
-                    mx = l[k];
-            }
-        }
-        mx = wave_max_f32(mx);
-        float part = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = lane + 64 * k;
-            ex[k] = 0.0f;
-            if (k < rounds && j < M) {
-                ex[k] = det_expf(l[k] - mx);
-                part = part + ex[k];
-            }
-        }
-        const float S = wave_sum_f32(part);
         float pr[4];
+        if (P.flags & AZH_FLAG_PY_POSTERIOR) {
+            // engine.py:197-203: softmax over all 833 logits, gather the legal moves, divide by
+            // (their sum + 1e-6)
+            float la[14];
+            float mx = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            pr[k] = S > 0.0f ? ex[k] / S : ex[k];
+            for (int t = 0; t < 14; t++) {
+                const int i = lane + 64 * t;
+                la[t] = i < AZH_POLICY_SIZE ? row[i] : -INFINITY;
+                if (la[t] > mx)
+                    mx = la[t];
+            }
+            mx = wave_max_f32(mx);
+            float part = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 14; t++)
+                if (lane + 64 * t < AZH_POLICY_SIZE)
+                    part = part + det_expf(la[t] - mx);
+            const float S = wave_sum_f32(part);
+            float lpart = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = lane + 64 * k;
+                ex[k] = 0.0f;
+                if (k < rounds && j < M) {
+                    ex[k] = det_expf(row[policy_index(A.em[first + j])] - mx) / S;
+                    lpart = lpart + ex[k];
+                }
+            }
+            const float den = wave_sum_f32(lpart) + 1e-6f;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                pr[k] = ex[k] / den;
+        } else {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = lane + 64 * k;
+                l[k] = -INFINITY;
+                if (k < rounds && j < M) {
+                    l[k] = row[policy_index(A.em[first + j])];
+                    if (l[k] > mx)
+                        mx = l[k];
+                }
+            }
+            mx = wave_max_f32(mx);
+            float part = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = lane + 64 * k;
+                ex[k] = 0.0f;
+                if (k < rounds && j < M) {
+                    ex[k] = det_expf(l[k] - mx);
+                    part = part + ex[k];
+                }
+            }
+            const float S = wave_sum_f32(part);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                pr[k] = S > 0.0f ? ex[k] / S : ex[k];
+        }
         if (kind == AZH_LEAF_ROOT && P.noise_w > 0.0f) {
             float gm[4];
             float gpart = 0.0f;
@@ -432,6 +480,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
 {
     __shared__ u16 s_moves[MAX_MOVES];
     __shared__ u32 s_old[WAVE], s_pref[WAVE + 1];
+    __shared__ u64 s_w[MAX_MOVES];
     const int g = blockIdx.x, lane = threadIdx.x;
     azh_game_state s = P.gs[g];
     // while (root.all_edge_visits < global_visits) step();  (:522-525)
@@ -460,16 +509,53 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
         }
     }
     int chosen = -1;
-    u32 run = 0;
+    if (P.flags & AZH_FLAG_SAMPLE_POW5) {
+        // sample_with_exponential_weight (engine.py:532-548), exponent 5: weights (n/N)^5 over
+        // edges with n >= max/2; the common 1/N^5 cancels, so the integers n^5 are exact.
+        u64 mk = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int j = lane + 64 * k;
-        const int incl = wave_incl_scan((int)ev[k].y);
-        const u32 cum = run + (u32)incl;
-        const u64 mask = __ballot(j < M && cum > r);
-        if (chosen < 0 && mask)
-            chosen = 64 * k + (__ffsll((long long)mask) - 1);
-        run += (u32)bcast_last(incl);
+        for (int k = 0; k < 4; k++)
+            mk = (u64)ev[k].y > mk ? (u64)ev[k].y : mk;
+        const u64 maxn = wave_max_u64(mk);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = lane + 64 * k;
+            if (j < M) {
+                const u64 n = ev[k].y;
+                s_w[j] = (2 * n >= maxn) ? n * n * n * n * n : 0ull;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            u64 T = 0;
+            for (int j = 0; j < M; j++)
+                T += s_w[j];
+            const u64 R = ((u64)rr.v[0] << 32) | (u64)rr.v[1];
+            const u64 rq = __umul64hi(R, T);
+            u64 cum = 0;
+            int c = -1;
+            for (int j = 0; j < M; j++) {
+                cum += s_w[j];
+                if (c < 0 && cum > rq)
+                    c = j;
+            }
+            s_pref[0] = (u32)c;
+        }
+        __syncthreads();
+        chosen = (int)s_pref[0];
+        __syncthreads();
+    } else {
+        u32 run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = lane + 64 * k;
+            const int incl = wave_incl_scan((int)ev[k].y);
+            const u32 cum = run + (u32)incl;
+            const u64 mask = __ballot(j < M && cum > r);
+            if (chosen < 0 && mask)
+                chosen = 64 * k + (__ffsll((long long)mask) - 1);
+            run += (u32)bcast_last(incl);
+        }
     }
     if (chosen < 0)
         chosen = 0;
@@ -491,7 +577,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
     const u32 my_mv = ck == 0 ? mvs[0] : (ck == 1 ? mvs[1] : (ck == 2 ? mvs[2] : mvs[3]));
     const u32 my_ch = ck == 0 ? ev[0].w : (ck == 1 ? ev[1].w : (ck == 2 ? ev[2].w : ev[3].w));
     const u32 mv = (u32)read_lane((int)my_mv, cl);
-    const u32 c = (u32)read_lane((int)my_ch, cl);
+    const u32 c = (P.flags & AZH_FLAG_NO_REUSE) ? NONE : (u32)read_lane((int)my_ch, cl);  // arena engines rebuild the tree every ply
     const ulonglong2 rootw = A.nb[0];
     if (lane == 0) {
         const u64 bx = rootw.x & ~TURN_BIT;
@@ -617,7 +703,8 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
     __syncthreads();
 
     u64 st_games = 0, st_dropped = 0, st_ring = 0;
-    if (result != 0) {
+    const bool cut = result == 0 && s.ply >= P.max_plies;
+    if (result != 0 || (cut && (P.flags & AZH_FLAG_KEEP_UNFINISHED))) {
         // finished: emit the packed record (generate_game :577-578, Worker :637-642)
         const u32 *recg = P.rec + (size_t)g * P.max_plies * REC_STRIDE_WORDS;
         int words = 0;
@@ -650,12 +737,13 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
                     out[pos + 6 + j] = rp[REC_HDR_WORDS + j];
                 pos += 6 + ndp;
             }
-            st_games = 1;
+            st_games = cut ? 0 : 1;
         } else {
             st_ring = 1;
         }
+        st_dropped = cut ? 1 : 0;  // arena: "invalid" -> annulled (uai_ringmaster.py:147-150)
         init_game(P, g, s.uid + (u32)P.G, s, s_moves);
-    } else if (s.ply >= P.max_plies) {
+    } else if (cut) {
         st_dropped = 1;  // null-result games are skipped (:628-631)
         init_game(P, g, s.uid + (u32)P.G, s, s_moves);
     } else {
@@ -714,7 +802,7 @@ using namespace azh;
 
 // ------------------------------------------------------------------ host
 
-std::string azh_format_game_json(const uint32_t *rec, size_t words);  // json.cpp
+std::string azh_format_game_json(const uint32_t *rec, size_t words, bool with_ids);  // json.cpp
 
 struct azh_engine {
     azh_config cfg;
@@ -733,6 +821,7 @@ struct azh_engine {
     std::vector<int> ev_evals;
     int *h_count = nullptr;  // pinned
     bool selected = false;
+    bool arena_lists = false;  // run_arena: one leaf list per net
 };
 
 static const size_t MAX_TIMED_ITERS = 4096;
@@ -776,6 +865,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     P.start_o = cfg->start_o;
     P.blockers = cfg->blockers;
     P.start_turn = cfg->start_turn;
+    P.flags = cfg->flags;
     const size_t G = (size_t)P.G;
     // ring of finished-game records (64 KiB per slot between two drains)
     P.ring_cap_words = std::max<size_t>((size_t)1 << 22, G * 16384);
@@ -792,6 +882,8 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.need_eval, G);
     rc |= dev_alloc(e, &P.leaf_list, G);
     rc |= dev_alloc(e, &P.leaf_count, 1);
+    rc |= dev_alloc(e, &P.leaf_list2, G);
+    rc |= dev_alloc(e, &P.leaf_count2, 1);
     rc |= dev_alloc(e, &P.logits, G * AZH_POLICY_SIZE);
     rc |= dev_alloc(e, &P.values, G);
     rc |= dev_alloc(e, &P.rec, G * P.max_plies * REC_STRIDE_WORDS);
@@ -841,8 +933,12 @@ extern "C" int azh_engine_edge_cap(const azh_engine *e) { return e ? e->P.edge_c
 static int enqueue_select(azh_engine *e)
 {
     hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->stream, e->P.need_eval, e->P.G, e->P.leaf_list,
-                       e->P.leaf_count);
+    const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->stream, (const int *)e->P.need_eval, e->P.G, e->P.leaf_list,
+                       e->P.leaf_count, 1, two ? 0 : 1);
+    if (two)
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->stream, (const int *)e->P.need_eval, e->P.G,
+                           e->P.leaf_list2, e->P.leaf_count2, 2, 0);
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -954,6 +1050,27 @@ extern "C" int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterat
     return 0;
 }
 
+extern "C" int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations)
+{
+    if (!e || !net_a || !net_b || iterations < 0)
+        return azh_fail(-1, "azh_engine_run_arena: bad argument");
+    if (!(e->P.flags & AZH_FLAG_TWO_NETS))
+        return azh_fail(-2, "azh_engine_run_arena: engine was not created with AZH_FLAG_TWO_NETS");
+    e->arena_lists = true;
+    for (int it = 0; it < iterations; it++) {
+        if (enqueue_select(e)) return -1;
+        int rc = azh_net_launch(net_a, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list, e->P.leaf_count,
+                                e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
+        if (rc == 0)
+            rc = azh_net_launch(net_b, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list2,
+                                e->P.leaf_count2, e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
+        if (rc) return rc;
+        if (enqueue_backup(e)) return -1;
+    }
+    e->arena_lists = false;
+    return 0;
+}
+
 extern "C" int azh_engine_sync(azh_engine *e)
 {
     if (!e)
@@ -1062,7 +1179,8 @@ extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int6
             }
             std::sort(order.begin(), order.end());
             for (auto &o : order)
-                e->pending.push_back(azh_format_game_json(host.data() + o.second, host[o.second + 5]));
+                e->pending.push_back(azh_format_game_json(host.data() + o.second, host[o.second + 5],
+                                                          (e->P.flags & AZH_FLAG_TWO_NETS) != 0));
         }
     }
     while (e->pending_pos < e->pending.size()) {

@@ -35,7 +35,8 @@ static void append_double(double v, std::string &out)
 // rec: ring record (engine.hip k_advance): 8-word header {magic, slot, uid, plies,
 // result, words, 0, 0} then per ply {x lo, x hi, o lo, o hi, move | nd << 16, 0,
 // nd x (move | visits << 16)}.
-std::string azh_format_game_json(const uint32_t *rec, size_t words)
+// with_ids (arena): two extra keys, "slot" and "uid", so the caller can tell which net had x.
+std::string azh_format_game_json(const uint32_t *rec, size_t words, bool with_ids)
 {
     const uint32_t plies = rec[3], result = rec[4];
     std::string boards = "[", dists = "[", moves = "[";
@@ -85,6 +86,8 @@ std::string azh_format_game_json(const uint32_t *rec, size_t words)
     }
     std::string out = "{\"boards\":" + boards + "],\"dists\":" + dists + "],\"moves\":" + moves + "],\"result\":";
     out += std::to_string(result);
+    if (with_ids)
+        out += ",\"slot\":" + std::to_string(rec[1]) + ",\"uid\":" + std::to_string(rec[2]);
     out += '}';
     return out;
 }

@@ -23,6 +23,8 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16,
           "f16": DTYPE_F16, "fp16": DTYPE_F16}
 LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
+FLAG_NO_REUSE, FLAG_TIE_FIRST, FLAG_PY_POSTERIOR, FLAG_SAMPLE_POW5, FLAG_KEEP_UNFINISHED, FLAG_TWO_NETS = 1, 2, 4, 8, 16, 32
+FLAG_ARENA = 63
 STAT_NAMES = ["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
               "edge_overflow", "reroot_nodes", "reroot_edges", "ring_overflow"]
 
@@ -36,7 +38,8 @@ class Config(ctypes.Structure):
                 ("edges_per_node", ctypes.c_int32), ("c_puct", ctypes.c_float),
                 ("dirichlet_alpha", ctypes.c_float), ("dirichlet_weight", ctypes.c_float),
                 ("start_turn", ctypes.c_int32), ("seed", ctypes.c_uint64), ("start_x", ctypes.c_uint64),
-                ("start_o", ctypes.c_uint64), ("blockers", ctypes.c_uint64)]
+                ("start_o", ctypes.c_uint64), ("blockers", ctypes.c_uint64),
+                ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class GameState(ctypes.Structure):
@@ -83,6 +86,7 @@ SIGNATURES = {
     "azh_engine_set_evals": (ctypes.c_int, [_vp, _vp, _vp]),
     "azh_engine_backup": (ctypes.c_int, [_vp]),
     "azh_engine_run": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "azh_engine_run_arena": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     "azh_engine_sync": (ctypes.c_int, [_vp]),
     "azh_engine_game_state": (ctypes.c_int, [_vp, ctypes.c_int, _P(GameState)]),
     "azh_engine_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
@@ -319,6 +323,9 @@ class Engine:
 
     def run(self, net, iterations, dtype=DTYPE_BF16):
         check(load().azh_engine_run(self.h, net.h, dtype, iterations))
+
+    def run_arena(self, net_a, net_b, iterations, dtype=DTYPE_BF16):
+        check(load().azh_engine_run_arena(self.h, net_a.h, net_b.h, dtype, iterations))
 
     def sync(self):
         check(load().azh_engine_sync(self.h))

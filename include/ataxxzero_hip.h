@@ -124,7 +124,25 @@ typedef struct {
     int32_t start_turn;
     uint64_t seed;
     uint64_t start_x, start_o, blockers; /* STARTING_GAME_POSITION (:23) */
+    uint32_t flags;          /* AZH_FLAG_*; 0 = the C++ self-play generator's behaviour */
+    uint32_t reserved;
 } azh_config;
+
+/* Behaviour switches that turn the self-play search into the arena search, i.e. the
+ * Python engine the reference's uai_ringmaster.py drives (engine.py, uai_interface.py): */
+enum {
+    AZH_FLAG_NO_REUSE = 1,        /* fresh tree every ply: with per-ply "moves" messages engine.set_state
+                                     (engine.py:452-472) never finds its grand-child and rebuilds the tree */
+    AZH_FLAG_TIE_FIRST = 2,       /* python max(): first maximal move (engine.py:291), not the C++ last (:354) */
+    AZH_FLAG_PY_POSTERIOR = 4,    /* 833-way softmax, gather, / (sum_legal + 1e-6) (engine.py:197-203) */
+    AZH_FLAG_SAMPLE_POW5 = 8,     /* move ~ (n/N)^5 over edges with n >= max/2 (engine.py:532-548, exponent 5
+                                     at uai_interface.py:76-79) */
+    AZH_FLAG_KEEP_UNFINISHED = 16,/* games cut at max_plies are reported with result 0 ("invalid" ->
+                                     annulled, uai_ringmaster.py:147-150) instead of dropped */
+    AZH_FLAG_TWO_NETS = 32,       /* arena: the side to move alternates between two nets; slot parity picks
+                                     which net plays x; records carry "slot" and "uid" */
+    AZH_FLAG_ARENA = 1 | 2 | 4 | 8 | 16 | 32
+};
 
 typedef struct {
     int32_t phase, arena, n_nodes, n_edges, ply, root_visits, leaf_kind, leaf_node, path_len;
@@ -170,6 +188,9 @@ int azh_engine_backup(azh_engine *e);
 
 /* `iterations` full iterations with the built-in net, enqueued asynchronously */
 int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations);
+/* arena (AZH_FLAG_TWO_NETS): net_a plays x in even slots and o in odd slots, net_b the
+ * other way round (uai_ringmaster.py:241-247 queues every pairing both ways) */
+int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations);
 int azh_engine_sync(azh_engine *e);
 
 int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out);

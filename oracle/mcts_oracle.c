@@ -186,6 +186,14 @@ static void select_game(orc_engine *e, int g)
     int a = s->arena;
     s->path_len = 0;
     if (s->phase == ORC_PHASE_ROOT_EVAL) {
+        if ((e->cfg.flags & ORC_FLAG_TWO_NETS) && (NI(e, a, g)[1] & 0xFFFFu) == 1) {
+            /* arena: a single legal move is played without search (uai_ringmaster.py:114-116) */
+            s->leaf_kind = ORC_LEAF_NONE;
+            s->leaf_node = 0;
+            s->phase = ORC_PHASE_SEARCH;
+            e->force[g] = 1;
+            return;
+        }
         s->leaf_kind = ORC_LEAF_ROOT;
         s->leaf_node = 0;
         st[ORC_STAT_NN_EVALS]++;
@@ -225,7 +233,8 @@ static void select_game(orc_engine *e, int g)
             float q = n ? W / (float)n : 0.0f;
             float u = (sq / (1.0f + (float)n)) * (e->cfg.c_puct * P);
             float score = u + q;
-            if (score > best || (score == best && j > bj)) { /* ties: last maximal (:354) */
+            /* ties: last maximal (:354); python's max() keeps the first (engine.py:291) */
+            if (score > best || (score == best && j > bj && !(e->cfg.flags & ORC_FLAG_TIE_FIRST))) {
                 best = score;
                 bj = j;
             }
@@ -276,8 +285,11 @@ int orc_engine_select(orc_engine *e, int32_t *need_eval)
         select_game(e, g);
         int k = e->gs[g].leaf_kind;
         int need = (k == ORC_LEAF_EVAL || k == ORC_LEAF_ROOT);
+        /* arena: the side to move alternates between net A (1) and net B (2); even slots give x to A */
+        if (need && (e->cfg.flags & ORC_FLAG_TWO_NETS))
+            need = 1 + ((e->gs[g].ply + g) & 1);
         if (need_eval) need_eval[g] = need;
-        count += need;
+        count += need != 0;
     }
     return count;
 }
@@ -318,17 +330,34 @@ static void apply_priors(orc_engine *e, int g, const float *logits, int root)
     uint32_t *ed = ED(e, a, g) + 4 * (size_t)first;
     const uint16_t *em = EM(e, a, g) + first;
     float l[ORC_MAX_MOVES], ex[ORC_MAX_MOVES];
-    float mx = -INFINITY;
-    for (int j = 0; j < M; j++) {
-        l[j] = logits[orc_policy_index(em[j])];
-        if (l[j] > mx) mx = l[j];
-    }
-    for (int j = 0; j < M; j++)
-        ex[j] = orc_det_expf(l[j] - mx);
-    float S = wave_sum(ex, M);
     float P[ORC_MAX_MOVES];
-    for (int j = 0; j < M; j++)
-        P[j] = S > 0.0f ? ex[j] / S : ex[j];
+    if (e->cfg.flags & ORC_FLAG_PY_POSTERIOR) {
+        /* engine.py:197-203: softmax over all 833 logits, gather the legal moves, divide by
+         * (their sum + 1e-6) */
+        float all[833];
+        float mx = -INFINITY;
+        for (int i = 0; i < 833; i++)
+            if (logits[i] > mx) mx = logits[i];
+        for (int i = 0; i < 833; i++)
+            all[i] = orc_det_expf(logits[i] - mx);
+        float S = wave_sum(all, 833);
+        for (int j = 0; j < M; j++)
+            ex[j] = orc_det_expf(logits[orc_policy_index(em[j])] - mx) / S;
+        float den = wave_sum(ex, M) + 1e-6f;
+        for (int j = 0; j < M; j++)
+            P[j] = ex[j] / den;
+    } else {
+        float mx = -INFINITY;
+        for (int j = 0; j < M; j++) {
+            l[j] = logits[orc_policy_index(em[j])];
+            if (l[j] > mx) mx = l[j];
+        }
+        for (int j = 0; j < M; j++)
+            ex[j] = orc_det_expf(l[j] - mx);
+        float S = wave_sum(ex, M);
+        for (int j = 0; j < M; j++)
+            P[j] = S > 0.0f ? ex[j] / S : ex[j];
+    }
     if (root && e->cfg.dirichlet_weight > 0.0f) {
         float gm[ORC_MAX_MOVES];
         uint32_t k0 = (uint32_t)e->cfg.seed, k1 = (uint32_t)(e->cfg.seed >> 32);
@@ -412,13 +441,35 @@ static void advance_game(orc_engine *e, int g)
     orc_philox((uint32_t)e->cfg.seed, (uint32_t)(e->cfg.seed >> 32), s->uid, (uint32_t)s->ply,
                ORC_STREAM_SAMPLE, 0, rnd);
     uint32_t N = (uint32_t)s->root_visits;
-    uint32_t r = (uint32_t)(((uint64_t)rnd[0] * N) >> 32);
     int chosen = -1;
-    uint32_t cum = 0;
-    for (int j = 0; j < M; j++) {
-        cum += ed[4 * (first + j) + 1];
-        if (chosen < 0 && cum > r)
-            chosen = j;
+    if (e->cfg.flags & ORC_FLAG_SAMPLE_POW5) {
+        /* sample_with_exponential_weight (engine.py:532-548), exponent 5: weights (n/N)^5 over
+         * edges with n >= max/2; the common 1/N^5 cancels, so integers n^5 are exact */
+        uint32_t maxn = 0;
+        for (int j = 0; j < M; j++)
+            if (ed[4 * (first + j) + 1] > maxn) maxn = ed[4 * (first + j) + 1];
+        uint64_t T = 0, w[ORC_MAX_MOVES];
+        for (int j = 0; j < M; j++) {
+            uint64_t n = ed[4 * (first + j) + 1];
+            w[j] = (2 * n >= maxn) ? n * n * n * n * n : 0;
+            T += w[j];
+        }
+        uint64_t R = ((uint64_t)rnd[0] << 32) | rnd[1];
+        uint64_t r = (uint64_t)(((unsigned __int128)R * T) >> 64);
+        uint64_t cum = 0;
+        for (int j = 0; j < M; j++) {
+            cum += w[j];
+            if (chosen < 0 && cum > r)
+                chosen = j;
+        }
+    } else {
+        uint32_t r = (uint32_t)(((uint64_t)rnd[0] * N) >> 32);
+        uint32_t cum = 0;
+        for (int j = 0; j < M; j++) {
+            cum += ed[4 * (first + j) + 1];
+            if (chosen < 0 && cum > r)
+                chosen = j;
+        }
     }
     if (chosen < 0)
         chosen = 0;
@@ -445,6 +496,8 @@ static void advance_game(orc_engine *e, int g)
     /* play (:475-492): keep the chosen child's subtree, copied breadth-first
      * into the other arena. */
     uint32_t c = ed[4 * (size_t)(first + chosen) + 3];
+    if (e->cfg.flags & ORC_FLAG_NO_REUSE)
+        c = NONE;  /* the arena engines rebuild their tree every ply (engine.py:452-472) */
     uint32_t *ni2 = NI(e, b, g), *ed2 = ED(e, b, g);
     uint16_t *em2 = EM(e, b, g);
     uint64_t *nb2 = NB(e, b, g);
@@ -504,6 +557,8 @@ static void advance_game(orc_engine *e, int g)
         init_game(e, g, s->uid + (uint32_t)e->G);
     } else if (s->ply >= e->cfg.max_plies) {
         st[ORC_STAT_DROPPED]++; /* null-result games are skipped (:628-631) */
+        if (e->cfg.flags & ORC_FLAG_KEEP_UNFINISHED)
+            finish_game(e, g, 0); /* arena: "invalid" -> annulled (uai_ringmaster.py:147-150) */
         init_game(e, g, s->uid + (uint32_t)e->G);
     } else {
         s->phase = ORC_PHASE_ROOT_EVAL;

@@ -34,7 +34,14 @@ typedef struct {
     int32_t start_turn;
     uint64_t seed;
     uint64_t start_x, start_o, blockers; /* STARTING_GAME_POSITION (:23) */
+    uint32_t flags;           /* ORC_FLAG_*: the arena variants of the search (engine.py) */
+    uint32_t reserved;
 } orc_config;
+
+enum {
+    ORC_FLAG_NO_REUSE = 1, ORC_FLAG_TIE_FIRST = 2, ORC_FLAG_PY_POSTERIOR = 4, ORC_FLAG_SAMPLE_POW5 = 8,
+    ORC_FLAG_KEEP_UNFINISHED = 16, ORC_FLAG_TWO_NETS = 32, ORC_FLAG_ARENA = 63
+};
 
 enum { ORC_LEAF_NONE = 0, ORC_LEAF_EVAL = 1, ORC_LEAF_TERMINAL = 2, ORC_LEAF_ROOT = 3 };
 enum { ORC_PHASE_ROOT_EVAL = 0, ORC_PHASE_SEARCH = 1 };
@@ -70,6 +77,7 @@ int orc_engine_edge_cap(const orc_engine *e);
 /* phase 1 of an iteration: select/expand in every game; returns #leaves needing
  * the evaluator.  need_eval[g] (optional) = 1 for those games. */
 int orc_engine_select(orc_engine *e, int32_t *need_eval);
+/* with ORC_FLAG_TWO_NETS need_eval[g] is 1 (net A) or 2 (net B) for the side to move */
 /* (mover, opponent) bitboards of every game's leaf, [G][2] */
 void orc_engine_leaf_boards(const orc_engine *e, uint64_t *out);
 /* reference feature rows (cpp/self_play_client.cpp:174-202) for game g's leaf */

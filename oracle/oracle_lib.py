@@ -15,6 +15,8 @@ STAT_NAMES = ["steps", "nn_evals", "levels", "children", "new_moves", "plies", "
               "edge_overflow", "reroot_nodes", "reroot_edges"]
 STAT_COUNT = 16
 LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
+FLAG_NO_REUSE, FLAG_TIE_FIRST, FLAG_PY_POSTERIOR, FLAG_SAMPLE_POW5, FLAG_KEEP_UNFINISHED, FLAG_TWO_NETS = 1, 2, 4, 8, 16, 32
+FLAG_ARENA = 63
 
 
 class Pos(ctypes.Structure):
@@ -27,7 +29,8 @@ class Config(ctypes.Structure):
                 ("edges_per_node", ctypes.c_int32), ("c_puct", ctypes.c_float),
                 ("dirichlet_alpha", ctypes.c_float), ("dirichlet_weight", ctypes.c_float),
                 ("start_turn", ctypes.c_int32), ("seed", ctypes.c_uint64), ("start_x", ctypes.c_uint64),
-                ("start_o", ctypes.c_uint64), ("blockers", ctypes.c_uint64)]
+                ("start_o", ctypes.c_uint64), ("blockers", ctypes.c_uint64),
+                ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class GameState(ctypes.Structure):
@@ -151,11 +154,11 @@ START_FEN_PLAIN = "x5o/7/7/7/7/7/o5x x"               # ataxx_rules.py:44-50
 
 
 def make_config(games, visits, seed=20260101, fen_str=START_FEN_SELFPLAY, max_plies=400,
-                edges_per_node=96, c_puct=1.0, alpha=0.15, weight=0.25):
+                edges_per_node=96, c_puct=1.0, alpha=0.15, weight=0.25, flags=0):
     p = pos_from_fen(fen_str)
     return Config(games=games, visits=visits, max_plies=max_plies, edges_per_node=edges_per_node,
                   c_puct=c_puct, dirichlet_alpha=alpha, dirichlet_weight=weight, start_turn=p.turn,
-                  seed=seed, start_x=p.pieces[0], start_o=p.pieces[1], blockers=p.blockers)
+                  seed=seed, start_x=p.pieces[0], start_o=p.pieces[1], blockers=p.blockers, flags=flags)
 
 
 def parse_game_record(buf):

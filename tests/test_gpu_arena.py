@@ -1,0 +1,118 @@
+"""Arena (config 5): the HIP engine with the arena flags against the oracle, bit for bit,
+plus the batched two-net match and the uai_ringmaster.py drop-in."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ataxxzero_amd import arena, link, model
+from oracle import oracle_lib as orc
+from tests.helpers import replay_game_entry, synthetic_evals
+from tests.test_gpu_engine import compare_all
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_arena_lockstep(games, visits, max_plies, iterations, seed):
+    ocfg = orc.make_config(games=games, visits=visits, seed=seed, fen_str=orc.START_FEN_PLAIN, max_plies=max_plies,
+                           weight=0.0, flags=orc.FLAG_ARENA)
+    gcfg = link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_})
+    oe, ge = orc.Engine(ocfg), link.Engine(gcfg)
+    o_games, g_lines = [], []
+    classes = set()
+    for it in range(iterations):
+        n_o, need_o = oe.select()
+        n_g = ge.select()
+        need_g, lb_g = ge.leaves()
+        assert n_o == n_g and (need_o == need_g).all(), it
+        classes |= set(need_o.tolist())
+        logits, values = synthetic_evals(oe.leaf_boards())
+        oe.backup(logits, values)
+        ge.set_evals(logits, values)
+        ge.backup()
+        if it % 197 == 0:
+            compare_all(oe, ge, range(games))
+        o_games += oe.pop_games()
+        g_lines += ge.drain_json()
+    compare_all(oe, ge, range(games))
+    assert {1, 2} <= classes <= {0, 1, 2}
+    so, sg = oe.stats(), ge.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    assert so["reroot_nodes"] == 0  # fresh tree every ply
+    assert len(g_lines) == len(o_games)
+    parsed = sorted((json.loads(l) for l in g_lines), key=lambda e: e["uid"])
+    for e, rec in zip(parsed, sorted(o_games, key=lambda r: r["uid"])):
+        assert e["slot"] == rec["slot"] and e["uid"] == rec["uid"]
+        assert {k: e[k] for k in ("boards", "dists", "moves", "result")} == rec["entry"]
+    return [json.loads(l) for l in g_lines], so
+
+
+def test_arena_search_matches_oracle_bit_for_bit():
+    games, stats = run_arena_lockstep(games=10, visits=8, max_plies=400, iterations=4200, seed=31)
+    assert len(games) >= 8 and stats["dropped"] == 0
+    for e in games:
+        assert e["result"] in (1, 2)
+        assert replay_game_entry({"boards": e["boards"], "moves": e["moves"]}, orc.START_FEN_PLAIN) == e["result"]
+
+
+def test_arena_games_cut_at_max_plies_are_reported_as_annulled():
+    games, stats = run_arena_lockstep(games=6, visits=6, max_plies=30, iterations=700, seed=4)
+    assert len(games) >= 6 and stats["dropped"] == len([e for e in games if e["result"] == 0]) > 0
+    for e in games:
+        if e["result"] == 0:
+            assert len(e["moves"]) == 30
+
+
+def test_batched_two_net_match_bookkeeping():
+    conv, bn = model.random_init(2, 128, seed=21)
+    conv2, bn2 = model.random_init(2, 128, seed=22)
+    m = arena.Match((conv, bn), (conv2, bn2), visits=16, games=128, dtype="bf16", seed=5, max_plies=300)
+    games = []
+    for _ in range(400):
+        m.run(50)
+        games += m.drain()
+        if len(games) >= 100:
+            break
+    st = m.engine.stats()
+    m.close()
+    assert len(games) >= 100 and st["reroot_nodes"] == 0
+    assert {g["white"] for g in games} == {"a", "b"}  # every pairing is played both ways
+    finished = [g for g in games if g["result"] in (1, 2)]
+    assert len(finished) >= 3 and all(g["result"] in (0, 1, 2) for g in games)
+    for g in finished[:30]:
+        assert replay_game_entry({"boards": g["boards"], "moves": g["moves"]}, orc.START_FEN_PLAIN) == g["result"]
+        x, o = g["final_score"]
+        assert 0 <= x <= 49 and 0 <= o <= 49 and (x + o == 49 or x == 0 or o == 0 or g["result"] in (1, 2))
+    for g in games:
+        if g["result"] == 0:
+            assert len(g["moves"]) == 300  # cut -> annulled
+
+
+def test_uai_ringmaster_cli(tmp_path):
+    conv, bn = model.random_init(1, 128, seed=2)
+    conv2, bn2 = model.random_init(1, 128, seed=3)
+    pa, pb = str(tmp_path / "model-001.npy"), str(tmp_path / "model-002.npy")
+    model.save_model(pa, conv, bn)
+    model.save_model(pb, conv2, bn2)
+    pgn = str(tmp_path / "out.pgn")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "uai_ringmaster.py"),
+                          "--engine", "python uai_interface.py --network-path %s --visits 16" % pa,
+                          "--engine", "python uai_interface.py --network-path %s --visits 16" % pb,
+                          "--pgn-out", pgn, "--game-count", "40", "--concurrent", "64"],
+                         cwd=ROOT, capture_output=True, timeout=400)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    out = res.stdout.decode()
+    wins = re.findall(r"Wins: ([0-9.]+) - ([0-9.]+) \(annulled: (\d+)\)", out)
+    assert len(wins) == 40
+    a, b, ann = float(wins[-1][0]), float(wins[-1][1]), int(wins[-1][2])
+    assert a + b == 40 and ann <= 40
+    text = open(pgn).read()
+    assert text.count('[Event "?"]') == 40 and text.count("[FinalScore ") == 40
+    assert re.search(r'\[Result "(1-0|0-1|1/2-1/2)"\]', text)
+    assert 'model-001.npy' in text and 'model-002.npy' in text

@@ -1,0 +1,88 @@
+#!/usr/bin/python
+"""Drop-in for the reference's uai_ringmaster.py on the path BASELINE.json scopes (config 5):
+a head-to-head match between two AtaxxZero nets, played as ONE batched, device-resident match
+on the GPU instead of UAI subprocess pairs.
+
+    python uai_ringmaster.py --engine "python uai_interface.py --network-path A.npy --visits 400" \\
+                             --engine "python uai_interface.py --network-path B.npy --visits 400" \\
+                             [--pgn-out games.pgn] [--max-plies N] [--game-count 1000]
+
+Same flags as the reference (uai_ringmaster.py:198-208); each --engine command is parsed for
+`--network-path` and `--visits` (the two options uai_interface.py:97-100 takes).  Prints the
+reference's `Wins: a - b (annulled: k)` line after every game and appends the reference's PGN
+blocks.  Foreign UAI engines, --opening, --gauntlet with more than two engines and --show-games
+need the subprocess ringmaster and are outside the GPU path.
+"""
+import argparse
+import shlex
+import sys
+
+from ataxxzero_amd import arena, model, selfplay
+
+
+def parse_engine(cmd):
+    p = argparse.ArgumentParser(add_help=False)
+    p.add_argument("--network-path", type=str, required=True)
+    p.add_argument("--visits", type=int, default=None)
+    known, _ = p.parse_known_args(cmd)
+    if known.visits is None:
+        raise SystemExit("uai_ringmaster.py: the GPU arena needs --visits in every engine command "
+                         "(time-controlled search depends on host speed)")
+    return known.network_path, known.visits
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--engine", metavar="CMD", action="append", help="Engine command.")
+    parser.add_argument("--show-games", action="store_true", help="(reference flag; not supported by the batched arena)")
+    parser.add_argument("--opening", metavar="MOVES", type=str, default=None, help="(reference flag; only the empty opening is supported)")
+    parser.add_argument("--max-plies", metavar="N", type=int, default=None, help="Maximum number of plies in a game before it's aborted and rejected.")
+    parser.add_argument("--pgn-out", metavar="PATH", type=str, default=None, help="PGN file path to accumulate games into. Writes in append mode.")
+    parser.add_argument("--gauntlet", action="store_true", help="Just the first engine plays against all the other engines.")
+    parser.add_argument("--tc", metavar="SEC", type=float, default=1.0, help="Seconds per move (recorded in the PGN; search is visit-limited).")
+    parser.add_argument("--game-count", metavar="N", type=int, default=1000, help="Stop after N games (extension: the reference loops forever).")
+    parser.add_argument("--concurrent", metavar="N", type=int, default=None, help="Games in flight on the GPU (extension).")
+    parser.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="Tower arithmetic (extension).")
+    parser.add_argument("--seed", type=int, default=selfplay.DEFAULT_SEED, help="Philox seed (extension).")
+    args = parser.parse_args()
+    print("Options:", args)
+    if not args.engine or len(args.engine) != 2:
+        raise SystemExit("uai_ringmaster.py: the GPU arena plays exactly two --engine commands against each other")
+    if args.show_games or (args.opening is not None and args.opening.strip()):
+        raise SystemExit("uai_ringmaster.py: --show-games / non-empty --opening are not supported by the batched arena")
+    engines = [tuple(shlex.split(e)) for e in args.engine]
+    print("Engines:")
+    for i, eng in enumerate(engines):
+        print("%4i: %s" % (i + 1, eng))
+    (path_a, visits_a), (path_b, visits_b) = parse_engine(engines[0]), parse_engine(engines[1])
+    if visits_a != visits_b:
+        raise SystemExit("uai_ringmaster.py: both engines must use the same --visits in the batched arena")
+    selfplay.select_device(0)
+    concurrent = args.concurrent or min(2048, args.game_count + args.game_count % 2)
+    concurrent += concurrent % 2
+    match = arena.Match(model.load_model(path_a), model.load_model(path_b), visits_a, games=concurrent, dtype=args.dtype,
+                        seed=args.seed, max_plies=args.max_plies if args.max_plies is not None else 400)
+    names = {"a": " ".join(engines[0]), "b": " ".join(engines[1])}
+    wins = {"a": 0, "b": 0}
+    annulled = 0
+    written = 0
+    while written < args.game_count:
+        match.run(25)
+        for game in sorted(match.drain(), key=lambda g: g["uid"]):
+            if written >= args.game_count:
+                break
+            white = game["white"]
+            black = "b" if white == "a" else "a"
+            print('Game: "%s" vs "%s" with opening: []' % (names[white], names[black]))
+            if game["result"] in (1, 2):
+                wins[white if game["result"] == 1 else black] += 1
+            else:
+                wins["a"] += 0.5
+                wins["b"] += 0.5
+                annulled += 1
+            print("Wins: %s (annulled: %i)" % (" - ".join(str(wins[k]) for k in ("a", "b")), annulled))
+            written += 1
+            if args.pgn_out:
+                arena.write_game_to_pgn(args.pgn_out, game, names[white], names[black], written, args.tc)
+        sys.stdout.flush()
+    match.close()
