@@ -1,0 +1,267 @@
+"""Training side of the loop on PyTorch-ROCm (reference train.py + model.py's training graph).
+
+Sample pipeline restated from train.py:11-89 (random game, random ply, side to move from ply
+parity, value target +-1, one of the 8 dihedral symmetries, policy target from `dists` or a
+one-hot of the move played), drawing from Python's `random` in the reference's order so the
+same games file gives the same minibatches.  Loss and optimiser from model.py:81-101: softmax
+cross-entropy on the 833 move logits + value MSE + 1e-4 * l2_loss over the trainable variables,
+Momentum(0.9).  The trained net is written in the reference's `.npy` layout (model.py:179-183).
+
+Q1: the reference trains batch-norm gamma/beta but never saves them, so
+the net it plays with is not the net it trained.  Here gamma = 1, beta = 0 are fixed
+(`affine=False`) by default — what is saved is exactly what was trained; `reference_bn_affine=True`
+restores the reference's train-then-drop behaviour.
+"""
+import json
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import model
+
+BOARD = model.BOARD_SIZE
+MOVE_TYPES = model.MOVE_TYPES
+# engine.py:75: layer of a jump = rank of (dx, dy) among the distance-2 offsets (ataxx_rules.py:17-20)
+FAR_OFFSETS = [(a, b) for a in (-2, -1, 0, 1, 2) for b in (-2, -1, 0, 1, 2)
+               if (a, b) != (0, 0) and (a, b) not in [(i, j) for i in (-1, 0, 1) for j in (-1, 0, 1)]]
+DELTA_LAYER = {d: i for i, d in enumerate(FAR_OFFSETS)}
+
+
+# ---------------------------------------------------------------- sample pipeline (train.py:11-89)
+
+def uai_decode_square(s):
+    return "abcdefg".index(s[0].lower()), 6 - (int(s[1]) - 1)          # uai_interface.py:19-22
+
+
+def uai_decode_move(s):
+    if s in ("pass", "none", "0000"):
+        return "pass"
+    if len(s) == 2:
+        return "c", uai_decode_square(s)
+    return uai_decode_square(s[:2]), uai_decode_square(s[2:])          # uai_interface.py:24-32
+
+
+def board_to_features(cells, to_move):
+    """engine.py:53-73 with BLOCKED_CELLS = frozenset(): planes ones / mover / opponent / blockers."""
+    f = np.zeros((BOARD, BOARD, 4), dtype=np.int8)
+    f[:, :, 0] = 1
+    for y in range(BOARD):
+        for x in range(BOARD):
+            piece = cells[x + y * BOARD]
+            if piece == to_move:
+                f[x, y, 1] = 1
+            elif piece != 0:
+                f[x, y, 2] = 1
+    return f
+
+
+def apply_symmetry(index, arr):
+    coin1, coin2, coin3 = index & 1, (index >> 1) & 1, (index >> 2) & 1   # train.py:11-23
+    arr = np.array(arr).copy()
+    if coin1:
+        arr = arr[::-1, :, :].copy()
+    if coin2:
+        arr = arr[:, ::-1, :].copy()
+    if coin3:
+        arr = np.swapaxes(arr.copy(), 0, 1).copy()
+    return arr
+
+
+def apply_symmetry_to_move(index, move):
+    coin1, coin2, coin3 = index & 1, (index >> 1) & 1, (index >> 2) & 1   # train.py:25-40
+
+    def coord(xy):
+        x, y = xy
+        if coin1:
+            x = (BOARD - 1) - x
+        if coin2:
+            y = (BOARD - 1) - y
+        if coin3:
+            x, y = y, x
+        return x, y
+
+    start, end = move
+    if start == "c":
+        return "c", coord(end)
+    return coord(start), coord(end)
+
+
+def add_move_to_heatmap(heatmap, move, coef=1):
+    start, end = move                                                     # engine.py:79-87
+    if start == "c":
+        heatmap[end[0], end[1], MOVE_TYPES - 1] += coef
+    else:
+        heatmap[end[0], end[1], DELTA_LAYER[(end[0] - start[0], end[1] - start[1])]] += coef
+
+
+def uai_encode_square(xy):
+    return "%s%i" % ("abcdefg"[xy[0]], (6 - xy[1]) + 1)
+
+
+def get_sample_from_entries(entries):
+    while True:                                                           # train.py:43-77
+        entry = random.choice(entries)
+        ply = random.randrange(len(entry["boards"]))
+        if "random_ply" in entry:
+            ply = entry["random_ply"] + 1
+        to_move = 1 if ply % 2 == 0 else 2
+        move = entry["moves"][ply]
+        if move == "pass":
+            continue
+        features = board_to_features(entry["boards"][ply], to_move)
+        desired_value = [1 if entry["result"] == to_move else -1]
+        symmetry_index = random.randrange(8)
+        features = apply_symmetry(symmetry_index, features)
+        desired_policy = np.zeros((BOARD, BOARD, MOVE_TYPES), dtype=np.float32)
+        if "dists" not in entry:
+            moves = [(move, 1)]
+        else:
+            moves = list(entry["dists"][ply].items())
+        for mv, probability in moves:
+            if isinstance(mv, str):
+                mv = uai_decode_move(mv)
+            else:
+                mv = (mv[0] if mv[0] == "c" else tuple(mv[0]), tuple(mv[1]))
+            add_move_to_heatmap(desired_policy, apply_symmetry_to_move(symmetry_index, mv), probability)
+        assert abs(1 - desired_policy.sum()) < 1e-3
+        return features, desired_policy, desired_value
+
+
+def load_entries(paths):
+    entries = []                                                          # train.py:79-89
+    for path in paths:
+        with open(path) as f:
+            for line in f:
+                line = line.strip()
+                if line:
+                    entries.append(json.loads(line))
+    random.shuffle(entries)
+    return entries
+
+
+def make_minibatch(entries, size):
+    feats, pols, vals = [], [], []
+    for _ in range(size):
+        f, p, v = get_sample_from_entries(entries)
+        feats.append(f)
+        pols.append(p)
+        vals.append(v)
+    return (np.asarray(feats, dtype=np.float32), np.asarray(pols, dtype=np.float32), np.asarray(vals, dtype=np.float32))
+
+
+# ---------------------------------------------------------------- the network (model.py:38-101)
+
+class Network(nn.Module):
+    """model.Network in NCHW: tensors are [n][c][x][y] (the reference's [n][x][y][c] permuted)."""
+
+    def __init__(self, blocks=12, filters=128, reference_bn_affine=False):
+        super().__init__()
+        self.blocks, self.filters = blocks, filters
+
+        def conv(cin, cout, k):
+            return nn.Conv2d(cin, cout, k, padding=k // 2, bias=False)
+
+        def bn():
+            # tf.layers.batch_normalization defaults: momentum 0.99 (torch: 1 - 0.99), epsilon 1e-3
+            return nn.BatchNorm2d(filters, eps=model.BN_EPSILON, momentum=0.01, affine=reference_bn_affine)
+
+        self.convs = nn.ModuleList([conv(4, filters, 3)] + [conv(filters, filters, 3) for _ in range(2 * blocks)])
+        self.bns = nn.ModuleList([bn() for _ in range(2 * blocks + 1)])
+        self.policy = conv(filters, MOVE_TYPES, 1)
+        self.value_conv = conv(filters, 1, 1)
+        self.fc = nn.Linear(BOARD * BOARD, 1)
+
+    def forward(self, x):
+        h = F.relu(self.bns[0](self.convs[0](x)))
+        for b in range(self.blocks):
+            t = F.relu(self.bns[1 + 2 * b](self.convs[1 + 2 * b](h)))
+            t = self.bns[2 + 2 * b](self.convs[2 + 2 * b](t))
+            h = F.relu(t + h)
+        policy = self.policy(h)                                            # [n][17][x][y]
+        v = self.value_conv(h).reshape(x.shape[0], BOARD * BOARD)          # index x*7 + y, as tf.reshape of [n,x,y,1]
+        value = torch.tanh(self.fc(v))
+        return policy.permute(0, 2, 3, 1), value                           # policy back to [n][x][y][17]
+
+    # .npy layout <-> torch: conv HWIO (i, j, c, o) <-> OIHW with H = x (i), W = y (j)
+    def load_numpy(self, conv_weights, bn_params):
+        with torch.no_grad():
+            convs = list(self.convs) + [self.policy, self.value_conv]
+            for m, w in zip(convs, conv_weights[:len(convs)]):
+                m.weight.copy_(torch.from_numpy(np.ascontiguousarray(np.transpose(w, (3, 2, 0, 1)))))
+            self.fc.weight.copy_(torch.from_numpy(np.asarray(conv_weights[-2]).reshape(1, BOARD * BOARD)))
+            self.fc.bias.copy_(torch.from_numpy(np.asarray(conv_weights[-1]).reshape(1)))
+            for i, m in enumerate(self.bns):
+                m.running_mean.copy_(torch.from_numpy(np.asarray(bn_params[2 * i])))
+                m.running_var.copy_(torch.from_numpy(np.asarray(bn_params[2 * i + 1])))
+
+    def to_numpy(self):
+        convs = list(self.convs) + [self.policy, self.value_conv]
+        cw = [np.ascontiguousarray(np.transpose(m.weight.detach().cpu().numpy(), (2, 3, 1, 0))) for m in convs]
+        cw.append(self.fc.weight.detach().cpu().numpy().reshape(BOARD * BOARD, 1).copy())
+        cw.append(self.fc.bias.detach().cpu().numpy().reshape(1).copy())
+        bn = []
+        for m in self.bns:
+            bn.append(m.running_mean.detach().cpu().numpy().copy())
+            bn.append(m.running_var.detach().cpu().numpy().copy())
+        return cw, bn
+
+
+def losses(net, features, policies, values):
+    """model.py:81-93: (policy cross-entropy, value MSE, 1e-4 * sum(l2_loss(w)) over trainable variables)."""
+    x = features.permute(0, 3, 1, 2)
+    logits, v = net(x)
+    n = features.shape[0]
+    logp = F.log_softmax(logits.reshape(n, -1), dim=1)
+    policy_loss = -(policies.reshape(n, -1) * logp).sum(dim=1).mean()
+    value_loss = ((values - v) ** 2).mean()
+    reg = 1e-4 * sum((p ** 2).sum() / 2 for p in net.parameters() if p.requires_grad)
+    return policy_loss, value_loss, reg
+
+
+def train(games_paths, old_path, new_path, steps=1000, minibatch_size=512, learning_rate=0.001, blocks=12, filters=128,
+          reference_bn_affine=False, device=None, log=print):
+    random.seed(123456789)                                                # train.py:103
+    entries = load_entries(games_paths)
+    ply_count = sum(len(e["moves"]) for e in entries)
+    log("Found %i games with %i plies." % (len(entries), ply_count))
+    test_entries, train_entries = entries[:10], entries[10:]
+    device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if old_path is not None:
+        log("Loading old model.")
+        cw, bnp = model.load_model(old_path)
+        blocks, filters = (len(cw) - 5) // 2, int(cw[0].shape[-1])
+    else:
+        log("WARNING: Not loading a previous model!")
+        cw, bnp = model.random_init(blocks, filters, seed=random.randrange(1 << 30))
+    net = Network(blocks, filters, reference_bn_affine).to(device)
+    net.load_numpy(cw, bnp)
+    opt = torch.optim.SGD(net.parameters(), lr=learning_rate, momentum=0.9)   # tf.train.MomentumOptimizer (model.py:99-100)
+
+    def to_dev(batch):
+        return tuple(torch.from_numpy(a).to(device) for a in batch)
+
+    random.seed(123456789)                                                # train.py:131
+    val_set = to_dev(make_minibatch(test_entries, 2048))
+    log("")
+    log("Model dimensions: %i filters, %i blocks, %i parameters." % (
+        filters, blocks, sum(int(np.prod(a.shape)) for a in cw)))
+    log("Have %i augmented samples, and sampling %i in total." % (ply_count * 8, steps * minibatch_size))
+    log("=== BEGINNING TRAINING ===")
+    for step_number in range(steps):
+        if step_number % 100 == 0:
+            net.eval()
+            with torch.no_grad():
+                pl, vl, _ = losses(net, *val_set)
+            log("Step: %4i -- loss: %.6f  (policy: %.6f  value: %.6f)" % (step_number, float(pl + vl), float(pl), float(vl)))
+        net.train()
+        batch = to_dev(make_minibatch(train_entries, minibatch_size))
+        pl, vl, reg = losses(net, *batch)
+        opt.zero_grad(set_to_none=True)
+        (pl + vl + reg).backward()
+        opt.step()
+    model.save_model(new_path, *net.to_numpy())
+    log("\x1b[35mSaved model to:\x1b[0m %s" % new_path)
+    return net
