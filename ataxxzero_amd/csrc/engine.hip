@@ -39,6 +39,7 @@ constexpr int REC_MAXD = 256;
 constexpr int REC_STRIDE_WORDS = REC_HDR_WORDS + REC_MAXD;
 constexpr u32 RING_MAGIC = 0x415A4847u;  // "AZHG"
 constexpr int NSTAT = AZH_STAT_COUNT;
+constexpr int BFS_QCAP = 2048;  // re-root frontier queue (LDS); bounds node_cap, i.e. visits <= 2040
 
 struct EngineParams {
     int G, visits, node_cap, edge_cap, path_cap, max_plies;
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
     __shared__ u16 s_moves[MAX_MOVES];
     __shared__ u32 s_old[WAVE], s_pref[WAVE + 1];
     __shared__ u64 s_w[MAX_MOVES];
+    __shared__ u32 q_old[BFS_QCAP], q_first[BFS_QCAP], q_info[BFS_QCAP], q_pe[BFS_QCAP];
     const int g = blockIdx.x, lane = threadIdx.x;
     azh_game_state s = P.gs[g];
     // while (root.all_edge_visits < global_visits) step();  (:522-525)
@@ -619,25 +621,29 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
     } else {
         const uint4 cinfo = A.ni[c];
         result = (int)(cinfo.y >> 16);
-        if (lane == 0) {
-            B.nb[0] = A.nb[c];
-            B.ni[0] = cinfo;
-        }
-        __syncthreads();
         // Breadth-first copy, up to 64 frontier nodes per pass.  Nodes are numbered in
         // (parent order, edge order) and a node's edges land at the running edge count,
         // exactly as the node-at-a-time loop of the oracle does, so the compacted arena is
-        // bit-identical — only the dependent-load chain is per pass instead of per node.
-        int *parent_edge = P.path + (size_t)g * P.path_cap;  // free between backup and select
+        // bit-identical.  The frontier (old node id, old edge range, parent edge) is queued in
+        // LDS when a child is discovered — its edge range comes from edge_kid, read in the same
+        // round trip as the edge — so one pass costs ONE dependent memory round trip.
         u32 t = 1, eb = 0, rv = 0, qs = 0;
+        if (lane == 0) {
+            q_old[0] = c;
+            q_first[0] = cinfo.x;
+            q_info[0] = cinfo.y;
+            q_pe[0] = 0;
+        }
+        __syncthreads();
         while (qs < t) {
             const u32 nchunk = min(t - qs, (u32)WAVE);
-            u32 of = 0, Mq = 0, qy = 0;
+            u32 of = 0, Mq = 0, qy = 0, old = 0, pe = 0;
             if ((u32)lane < nchunk) {
-                const uint4 qi = B.ni[qs + lane];
-                of = qi.x;
-                Mq = qi.y & 0xFFFFu;
-                qy = qi.y;
+                old = q_old[qs + lane];
+                of = q_first[qs + lane];
+                qy = q_info[qs + lane];
+                pe = q_pe[qs + lane];
+                Mq = qy & 0xFFFFu;
             }
             const u32 incl = (u32)wave_incl_scan((int)Mq);
             const u32 Ef = (u32)bcast_last((int)incl);
@@ -645,9 +651,11 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
                 const u32 nf = Mq ? eb + incl - Mq : 0u;
                 s_old[lane] = of;
                 s_pref[lane] = incl - Mq;
-                reinterpret_cast<u32 *>(&B.ni[qs + lane])[0] = nf;
+                // node copy: not on the dependent chain (nothing below waits for these loads)
+                B.nb[qs + lane] = A.nb[old];
+                B.ni[qs + lane] = make_uint4(nf, qy, 0u, A.ni[old].w);
                 if (qs + lane > 0)
-                    B.ek[parent_edge[qs + lane]] = make_uint2(nf, qy);
+                    B.ek[pe] = make_uint2(nf, qy);
             }
             if (lane == 0)
                 s_pref[nchunk] = Ef;
@@ -656,6 +664,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
                 const u32 e = e0 + (u32)lane;
                 const bool valid = e < Ef;
                 uint4 ed = make_uint4(0u, 0u, 0u, NONE);
+                uint2 kd = make_uint2(0u, 0u);
                 u16 m = 0;
                 if (valid) {
                     u32 lo = 0, hi = nchunk;  // largest i with s_pref[i] <= e
@@ -666,6 +675,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
                     }
                     const u32 src = s_old[lo] + (e - s_pref[lo]);
                     ed = A.ed[src];
+                    kd = A.ek[src];
                     m = A.em[src];
                     if (qs == 0 && lo == 0)
                         rv += ed.y;
@@ -675,9 +685,10 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
                 const u32 dst = eb + e;
                 if (has) {
                     const u32 nc = t + (u32)__popcll(mask & lt);
-                    B.nb[nc] = A.nb[ed.w];
-                    B.ni[nc] = A.ni[ed.w];
-                    parent_edge[nc] = (int)dst;
+                    q_old[nc] = ed.w;
+                    q_first[nc] = kd.x;
+                    q_info[nc] = kd.y;
+                    q_pe[nc] = dst;
                     ed.w = nc;
                 }
                 if (valid) {
@@ -840,7 +851,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
 {
     if (!cfg || !out)
         return azh_fail(-1, "azh_engine_create: null argument");
-    if (cfg->games <= 0 || cfg->visits <= 0 || cfg->visits > 60000 || cfg->max_plies <= 0 ||
+    if (cfg->games <= 0 || cfg->visits <= 0 || cfg->visits + 8 > BFS_QCAP || cfg->max_plies <= 0 ||
         cfg->edges_per_node < 8)
         return azh_fail(-2, "azh_engine_create: bad config (games %d visits %d max_plies %d edges_per_node %d)",
                         cfg->games, cfg->visits, cfg->max_plies, cfg->edges_per_node);
@@ -1068,6 +1079,17 @@ extern "C" int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_
         if (enqueue_backup(e)) return -1;
     }
     e->arena_lists = false;
+    return 0;
+}
+
+// Root-visit threshold for the coming moves (1 .. the value the engine was created with; the
+// arenas are sized for that).  Takes effect at the next k_advance.
+extern "C" int azh_engine_set_visits(azh_engine *e, int visits)
+{
+    if (!e || visits < 1 || visits > e->cfg.visits)
+        return azh_fail(-1, "azh_engine_set_visits: need 1 <= visits <= %d", e ? e->cfg.visits : 0);
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    e->P.visits = visits;
     return 0;
 }
 

@@ -88,6 +88,7 @@ SIGNATURES = {
     "azh_engine_run": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
     "azh_engine_run_arena": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     "azh_engine_sync": (ctypes.c_int, [_vp]),
+    "azh_engine_set_visits": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_game_state": (ctypes.c_int, [_vp, ctypes.c_int, _P(GameState)]),
     "azh_engine_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "azh_engine_stats": (ctypes.c_int, [_vp, _vp]),
@@ -113,7 +114,7 @@ def load():
     global _dll
     if _dll is not None:
         return _dll
-    path = _build.build()
+    path = os.environ.get("AZH_LIB") or _build.build()  # AZH_LIB: load a specific build (A/B runs)
     dll = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(dll, name)
@@ -329,6 +330,9 @@ class Engine:
 
     def sync(self):
         check(load().azh_engine_sync(self.h))
+
+    def set_visits(self, visits):
+        check(load().azh_engine_set_visits(self.h, visits))
 
     def game_state(self, g):
         s = GameState()

@@ -99,6 +99,10 @@ class SelfPlay:
         for e in self.engines:
             e.sync()
 
+    def set_visits(self, visits):
+        for e in self.engines:
+            e.set_visits(visits)
+
     def drain(self):
         lines = []
         for e in self.engines:

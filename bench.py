@@ -78,6 +78,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--chunk", type=int, default=250, help="iterations between finished-game drains")
     ap.add_argument("--streams", type=int, default=1, help="half-batches in flight per GPU (the reference's double buffer)")
+    ap.add_argument("--phase-mix", type=int, default=2500,
+                    help="untimed setup iterations at 16 sims/move that spread the games over all game phases "
+                         "(a fresh start has every game at ply 0 with an empty tree), followed by --phase-fill "
+                         "iterations at full sims/move that regrow the trees; then the --warmup steps")
+    ap.add_argument("--phase-fill", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -103,6 +108,11 @@ def main():
             done += n
         return finished
 
+    if args.phase_mix > 0:
+        sp.set_visits(min(16, args.visits))
+        run(args.phase_mix)
+        sp.set_visits(args.visits)
+        run(args.phase_fill)
     run(args.warmup)
     sp.sync()
     group.barrier()
@@ -140,6 +150,8 @@ def main():
                                    "(per-GPU shard of BASELINE configs[2]; configs[1] at the metric's 400 sims)"
                                    % (args.games, args.visits, args.blocks, args.dtype),
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
+                       "setup": "games spread over all phases by %d untimed 16-sim iterations + %d at full sims, then "
+                                "the warm-up" % (args.phase_mix, args.phase_fill if args.phase_mix > 0 else 0),
                        "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},
             "nn_evals_per_s": evals_total / t_max, "plies_per_s": plies_total / t_max,

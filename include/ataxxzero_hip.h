@@ -192,6 +192,9 @@ int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations);
  * other way round (uai_ringmaster.py:241-247 queues every pairing both ways) */
 int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations);
 int azh_engine_sync(azh_engine *e);
+/* change the root-visit threshold (global_visits) for the coming moves; 1 <= visits <= the
+ * value the engine was created with */
+int azh_engine_set_visits(azh_engine *e, int visits);
 
 int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out);
 /* arena dump: boards [n_nodes][2] u64, info [n_nodes][4] u32
