@@ -131,3 +131,42 @@ def test_two_half_batches_match_two_independent_engines():
             for x, y in zip(a.tree(g), b.tree(g)):
                 assert (x == y).all()
     sp.close()
+
+
+def test_looper_iteration_generate_train_generate(tmp_path):
+    """One iteration of looper.py's main loop (looper.py:117-153) with the two commands it issues:
+    accelerated_generate_games.py on model-001, train.py -> model-002, generation again on model-002."""
+    prefix = tmp_path / "run1"
+    (prefix / "games").mkdir(parents=True)
+    (prefix / "models").mkdir()
+    conv, bn = model.random_init(1, 128, seed=11)
+    m1, m2 = str(prefix / "models" / "model-001.npy"), str(prefix / "models" / "model-002.npy")
+    model.save_model(m1, conv, bn)
+
+    def generate(model_path, games_path, want):
+        open(games_path, "a").close()  # looper.py:24-25 touches the file first
+        proc = subprocess.Popen([sys.executable, "accelerated_generate_games.py", "--network", model_path,
+                                 "--output-games", games_path, "--visits", "8", "--buffer-size", "128"],
+                                cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        deadline = time.time() + 300
+        while time.time() < deadline and proc.poll() is None:
+            time.sleep(1.0)
+            if sum(1 for l in open(games_path) if l.strip()) >= want:  # looper.py:5-12 count_games
+                break
+        proc.send_signal(signal.SIGTERM)
+        out, _ = proc.communicate(timeout=30)
+        assert proc.returncode == 0, out.decode()[-2000:]
+        return sum(1 for l in open(games_path) if l.strip())
+
+    g1 = str(prefix / "games" / "model-001-0.json")
+    assert generate(m1, g1, 150) >= 150
+    res = subprocess.run([sys.executable, "train.py", "--steps", "20", "--minibatch-size", "128", "--games", g1,
+                          "--old-path", m1, "--new-path", m2], cwd=ROOT, capture_output=True, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    assert "Step:    0 -- loss:" in res.stdout.decode()
+    conv2, bn2 = model.load_model(m2)
+    assert any(not np.array_equal(a, b) for a, b in zip(conv, conv2))
+    g2 = str(prefix / "games" / "model-002-0.json")
+    assert generate(m2, g2, 60) >= 60
+    entry = json.loads(open(g2).readline())
+    assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
