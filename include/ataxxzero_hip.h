@@ -158,7 +158,8 @@ enum {
 typedef struct {
     /* sums of HIP-event elapsed milliseconds over the launches recorded since the
      * last azh_engine_timing_reset, and the number of iterations recorded */
-    double select_ms, net_ms, backup_ms;
+    double select_ms, net_ms, backup_ms; /* select_ms: the fused tree launch of the run loop (backup + advance +
+                                            select + compaction); backup_ms: 0 there */
     int64_t iterations;
     int64_t net_evals; /* leaves evaluated by the net in those iterations */
 } azh_timing;
