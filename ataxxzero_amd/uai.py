@@ -1,0 +1,134 @@
+"""Single-position search for the UAI front-end: what engine.MCTSEngine.genmove does
+(engine.py:474-530) with the tree, the search and the net on the GPU.
+
+One game slot, the Python engine's search semantics (first-max ties, 833-way posterior, no
+Dirichlet: AZH_FLAG_TIE_FIRST | AZH_FLAG_PY_POSTERIOR), a fresh tree per call — which is what
+the reference engine ends up with when a UAI master sends one `moves` message per ply
+(engine.set_state, engine.py:452-472).  With `visits` the search is exactly `visits` MCTS steps
+(uai_interface.py:44-46); with a time budget it runs until the time is used.  The move is then
+sampled on the host exactly like sample_with_exponential_weight (engine.py:532-548).
+"""
+import random
+import time
+
+import numpy as np
+
+from . import link, model, selfplay
+
+FILES = "abcdefg"
+
+
+def encode_square(sq):
+    return "%s%i" % (FILES[sq % 7], sq // 7 + 1)
+
+
+def encode_move(mv):
+    """u16 from | to << 8 -> UAI string (uai_interface.py:11-17); 0xFFFF -> "0000"."""
+    if mv == 0xFFFF:
+        return "0000"
+    frm, to = mv & 0xFF, mv >> 8
+    return encode_square(to) if frm == to else encode_square(frm) + encode_square(to)
+
+
+def decode_move(s):
+    """UAI string -> u16 (uai_interface.py:24-32)."""
+    if s in ("pass", "none", "0000"):
+        return 0xFFFF
+    sq = lambda t: FILES.index(t[0].lower()) + 7 * (int(t[1]) - 1)
+    if len(s) == 2:
+        return sq(s) | (sq(s) << 8)
+    if len(s) == 4:
+        return sq(s[:2]) | (sq(s[2:]) << 8)
+    raise Exception("Bad UAI move string: %r" % s)
+
+
+class Position:
+    """Board bookkeeping of the front-end, with the GPU rules behind it."""
+
+    def __init__(self, x, o, turn):
+        self.x, self.o, self.turn = x, o, turn
+
+    @staticmethod
+    def initial():
+        x, o, _, turn = selfplay.parse_fen(selfplay.START_FEN_PLAIN)
+        return Position(x, o, turn)
+
+    @staticmethod
+    def from_fen(fen):
+        x, o, bl, turn = selfplay.parse_fen(fen)
+        return Position(x, o, turn)
+
+    def packed(self):
+        return link.pack_board(self.x, self.o, self.turn)
+
+    def legal_moves(self):
+        moves, counts, results = link.rules_batch(self.packed().reshape(1, 2), 0)
+        return [int(m) for m in moves[0, :counts[0]]], int(results[0])
+
+    def move(self, mv):
+        out = link.makemove_batch(self.packed().reshape(1, 2), np.array([mv], dtype=np.uint16))[0]
+        self.x, self.o, self.turn = int(out[0]) & ~(1 << 63), int(out[1]), int(out[0]) >> 63
+
+    def __str__(self):
+        rows = []
+        for r in range(6, -1, -1):
+            rows.append(" ".join("X" if (self.x >> (f + 7 * r)) & 1 else ("O" if (self.o >> (f + 7 * r)) & 1 else ".")
+                                 for f in range(7)))
+        return "\n".join(rows)
+
+
+class Searcher:
+    TIME_CAP_VISITS = 20000  # arena size of a time-controlled search
+
+    def __init__(self, network_path, dtype="bf16"):
+        conv, bn = model.load_model(network_path)
+        self.net = link.Net(conv, bn, model.BN_EPSILON)
+        self.dtype = link.DTYPES[dtype]
+        self.last_steps = 0
+        self.last_seconds = 0.0
+
+    def root_visits(self, pos, visits=None, seconds=None):
+        """-> [(move u16, visits)] over the expanded root edges after the search."""
+        cap = visits if visits is not None else self.TIME_CAP_VISITS
+        cfg = link.Config(games=1, visits=cap + 1, max_plies=400, edges_per_node=96, c_puct=1.0, dirichlet_alpha=0.15,
+                          dirichlet_weight=0.0, start_turn=pos.turn, seed=random.getrandbits(63), start_x=pos.x,
+                          start_o=pos.o, blockers=0, flags=link.FLAG_TIE_FIRST | link.FLAG_PY_POSTERIOR)
+        eng = link.Engine(cfg)
+        start = time.time()
+        try:
+            if visits is not None:
+                eng.run(self.net, 1 + visits, self.dtype)  # root evaluation + `visits` steps
+                steps = visits
+            else:
+                eng.run(self.net, 2, self.dtype)
+                steps = 1
+                while time.time() - start < seconds and steps + 64 < cap:
+                    eng.run(self.net, 64, self.dtype)
+                    eng.sync()
+                    steps += 64
+            eng.sync()
+            boards, info, edges, moves = eng.tree(0)
+        finally:
+            eng.close()
+        self.last_steps, self.last_seconds = steps, max(time.time() - start, 1e-9)
+        first, n = int(info[0, 0]), int(info[0, 1] & 0xFFFF)
+        return [(int(moves[first + j]), int(edges[first + j, 1])) for j in range(n) if int(edges[first + j, 3]) != 0xFFFFFFFF]
+
+    def genmove(self, pos, visits=None, seconds=None, exponent=5.0):
+        legal, result = pos.legal_moves()
+        if not legal:
+            return 0xFFFF  # the reference answers "pass" when no edge was visited (engine.py:495-496)
+        edges = self.root_visits(pos, visits=visits, seconds=seconds)
+        if not edges:
+            return legal[0]
+        # sample_with_exponential_weight (engine.py:532-548)
+        total = float(sum(n for _, n in edges))
+        max_visits = max(n for _, n in edges)
+        weights = {mv: (n / total) ** exponent for mv, n in edges if n >= max_visits * 0.5}
+        norm = 1.0 / sum(weights.values())
+        x = random.random()
+        for mv, w in weights.items():  # sample_by_weight (engine.py:38-47)
+            if x <= w * norm:
+                return mv
+            x -= w * norm
+        return next(iter(weights))

@@ -170,3 +170,55 @@ def test_looper_iteration_generate_train_generate(tmp_path):
     assert generate(m2, g2, 60) >= 60
     entry = json.loads(open(g2).readline())
     assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+
+
+def test_uai_interface_engine_plays_legal_moves(tmp_path):
+    """The UAI protocol loop (uai_interface.py:41-88): handshake, per-ply `moves`, `go movetime`,
+    `position fen`, showboard; the answers must be legal in the tracked position."""
+    conv, bn = model.random_init(1, 128, seed=12)
+    path = str(tmp_path / "model-001.npy")
+    model.save_model(path, conv, bn)
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "uai_interface.py"), "--network-path", path, "--visits", "24"],
+                            cwd=ROOT, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def send(s):
+        proc.stdin.write(s + "\n")
+        proc.stdin.flush()
+
+    def read_until(prefix):
+        while True:
+            line = proc.stdout.readline()
+            assert line, proc.stderr.read()[-2000:]
+            if line.startswith(prefix):
+                return line.strip()
+
+    send("uai")
+    assert read_until("uaiok") == "uaiok"
+    send("isready")
+    assert read_until("readyok") == "readyok"
+    send("uainewgame")
+    p = orc.pos_from_fen(orc.START_FEN_PLAIN)
+    for ply in range(6):  # the ringmaster's flow: go -> bestmove -> `moves m` to every engine
+        send("go movetime 100")
+        best = read_until("bestmove ").split()[1]
+        legal = [orc.move_string(m) for m in orc.movegen(p)]
+        assert best in legal, (best, legal)
+        send("moves " + best)
+        c = orc.move_from_string(best)
+        orc.lib().orc_makemove(p, c & 0xFF, c >> 8)
+    send("showboard")
+    read_until("boardok")
+    send("position fen x5o/7/7/7/7/7/o5x o")
+    send("go movetime 100")
+    best = read_until("bestmove ").split()[1]
+    q = orc.pos_from_fen("x5o/7/7/7/7/7/o5x o")
+    assert best in [orc.move_string(m) for m in orc.movegen(q)]
+    send("quit")
+    proc.wait(timeout=30)
+    # codecs keep the reference's names and conventions (uai_interface.py:34-39)
+    sys.path.insert(0, ROOT)
+    import uai_interface
+    for s in ["f2", "c3d5"]:
+        assert uai_interface.uai_encode_move(uai_interface.uai_decode_move(s)) == s
+    for m in [("c", (4, 3)), ((4, 3), (2, 5))]:
+        assert uai_interface.uai_decode_move(uai_interface.uai_encode_move(m)) == m
