@@ -30,7 +30,7 @@ def compare_all(oe, ge, games):
             assert a.shape == b.shape and (a == b).all(), (g, name)
 
 
-def run_lockstep(oe, ge, iterations, check_every=1):
+def run_lockstep(oe, ge, iterations, check_every=1, evaluator=synthetic_evals):
     G = oe.G
     o_games, g_lines = [], []
     for it in range(iterations):
@@ -40,7 +40,7 @@ def run_lockstep(oe, ge, iterations, check_every=1):
         lb_o = oe.leaf_boards()
         assert n_o == n_g and (need_o == need_g).all(), it
         assert (lb_o[need_o == 1] == lb_g[need_o == 1]).all(), it
-        logits, values = synthetic_evals(lb_o)
+        logits, values = evaluator(lb_o)
         oe.backup(logits, values)
         ge.set_evals(logits, values)
         ge.backup()
@@ -116,3 +116,27 @@ def test_device_resident_selfplay_with_builtin_net():
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
         # root visit counts reach the threshold: each dist is k / N with N >= visits
         assert all(min(d.values()) > 0 for d in entry["dists"])
+
+
+def test_reroot_queue_spill_path_matches_oracle():
+    # visits > 512: kept subtrees grow past the LDS part of the re-root frontier queue, so the
+    # HBM spill path of advance_game is exercised; still bit-exact against the oracle
+    # (a steep prior over the policy index concentrates the visits on one line, so most of the tree is kept)
+    steep = lambda lb: (np.tile(-0.75 * np.arange(833, dtype=np.float32), (len(lb), 1)), np.zeros(len(lb), np.float32))
+    oe, ge = make_pair(games=2, visits=1200, seed=13, weight=0.0)
+    run_lockstep(oe, ge, 3700, check_every=600, evaluator=steep)
+    st = oe.stats()
+    assert st["plies"] >= 4 and st["reroot_nodes"] / st["plies"] > 520, st
+
+
+def test_odd_sizes_and_f16_device_loop():
+    conv, bn = model.random_init(1, 128, seed=4)
+    net = link.Net(conv, bn)
+    for games, visits in ((1, 5), (67, 9)):
+        ocfg = orc.make_config(games, visits, seed=2)
+        ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+        ge.run(net, 150, link.DTYPE_F16)
+        ge.sync()
+        st = ge.stats()
+        assert st["steps"] > 40 * games and st["plies"] > 5 * games and st["edge_overflow"] == 0
+        ge.close()
