@@ -98,20 +98,22 @@ template <int DT, int NB> struct Geo {
     static constexpr int BOARDS = NB;
     static constexpr int NC = 49 * BOARDS;             // real cells per workgroup
     static constexpr int NT = (NC + 31) / 32;          // 32-cell MFMA column tiles
-    static constexpr int Z = (DT != AZH_DTYPE_F32 && NB == 6) ? 16 : 8;   // zero slots (power of two)
-    static constexpr int NSLOT = NC + Z;
+    static constexpr int Z = 16;                       // zero slots per unit, shared by both images
+    static constexpr int NSLOT = 2 * NC + Z;           // slots of one unit: [image 0][zeros][image 1]
     static constexpr int UB = DT == AZH_DTYPE_F32 ? 4 : 16;               // bytes of one unit in one slot
     static constexpr int NUNIT = F * Tr::ESIZE / UB;                        // units per image
     static constexpr int CS = NSLOT * UB;              // byte stride between units
-    static constexpr int IMG = NUNIT * CS;             // one activation image
-    static constexpr int VCELL_OFF = NB * 833 * 4;     // value-cell scratch behind the staged logits (image 0)
-    static constexpr int LDS_BYTES = 2 * IMG;
+    static constexpr int VCELL_OFF = NUNIT * CS;       // f32 value-cell scratch behind the images
+    static constexpr int LDS_BYTES = VCELL_OFF + NC * 4;
     static constexpr int KSTEPS_FULL = F / Tr::KSTEP;  // k-steps per tap, 128-channel input
     static constexpr int KSTEPS_IN = (Tr::KSTEP >= 4) ? 1 : 4 / Tr::KSTEP;  // 4 input planes
-    static_assert(VCELL_OFF + NC * 4 <= IMG, "staging area must fit in one image");
-    // slot of cell c (c may be a neighbour index that fell off its board or a pad lane)
-    __device__ static int zero_slot(int c) { return NC + ((c - NC) & (Z - 1)); }
-    // byte offset of (slot, unit, byte) inside an image
+    // slot (within a unit) of cell c of image img
+    __device__ static int real_slot(int img, int c) { return img * (NC + Z) + c; }
+    // zero slot standing in for the off-board / pad cell index c of image img: the one with the
+    // same residue mod 16 as the slot c would have had, so a B-fragment read (16 lanes x 16 B per
+    // LDS pass) keeps every lane on its own banks
+    __device__ static int zero_slot(int img, int c) { return NC + ((img * NC + c - NC) & (Z - 1)); }
+    // byte offset of (slot, unit, byte)
     __device__ static int off(int slot, int unit, int byte = 0) { return unit * CS + slot * UB + byte; }
     // 16-bit types: channel ch lives in unit ch/8 at byte 2*(ch%8); f32: unit ch
     __device__ static int ch_off(int slot, int ch)
@@ -149,8 +151,8 @@ template <int I, int N, typename Fn> __device__ inline void static_for(Fn &&fn)
 }
 
 // One convolution layer for the workgroup's boards, KS k-steps per tap (compile time).
-// `in_off` / `out` / `skip` address the LDS images; lds is the start of dynamic LDS
-// (in_off is a multiple of the row size).
+// `in_img` / `out_img` pick the LDS images (0 / 1); with `skip` the layer adds the residual
+// input, i.e. the current content of the output image.
 __device__ inline unsigned long long stamp_now()
 {
     __builtin_amdgcn_sched_barrier(0);
@@ -160,7 +162,7 @@ __device__ inline unsigned long long stamp_now()
 }
 
 template <int DT, int NB, int KS, bool STAMP = false>
-__device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned char *out, const unsigned char *skip,
+__device__ inline void conv_layer(unsigned char *lds, int in_img, int out_img, bool skip,
                                   const typename Traits<DT>::afrag *__restrict__ wp,
                                   typename Traits<DT>::afrag (&a)[RING], f32x16 &sh, const float *__restrict__ shift_next,
                                   const int (&vmask)[Geo<DT, NB>::NT], int wave, int lane,
@@ -187,16 +189,16 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
 #pragma unroll
         for (int ct = 0; ct < NT; ct++) {
             const int cell = ct * 32 + r;
-            const int slot = cell < G::NC ? cell : G::zero_slot(cell);
+            const int slot = cell < G::NC ? G::real_slot(out_img, cell) : G::zero_slot(out_img, cell);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int ch = 32 * wave + 8 * q + 4 * h;
                 if constexpr (DT == AZH_DTYPE_F32) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        sk[ct][q][i] = *reinterpret_cast<const float *>(skip + G::ch_off(slot, ch + i));
+                        sk[ct][q][i] = *reinterpret_cast<const float *>(lds + G::ch_off(slot, ch + i));
                 } else {
-                    sk[ct][q] = *reinterpret_cast<const typename Tr::quad *>(skip + G::ch_off(slot, ch));
+                    sk[ct][q] = *reinterpret_cast<const typename Tr::quad *>(lds + G::ch_off(slot, ch));
                 }
             }
         }
@@ -239,8 +241,8 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
 #pragma unroll
         for (int ct = 0; ct < NT; ct++) {
             const int c = ct * 32 + r + drow;
-            const int slot = ((vmask[ct] >> tap) & 1) ? c : G::zero_slot(c);
-            dst[ct] = in_off + h * G::CS + slot * G::UB;
+            const int slot = ((vmask[ct] >> tap) & 1) ? G::real_slot(in_img, c) : G::zero_slot(in_img, c);
+            dst[ct] = h * G::CS + slot * G::UB;
         }
     };
     auto load_b = [&](afrag (&bf)[NT], const int (&rows)[NT], int ks) {
@@ -364,10 +366,10 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
                 if constexpr (DT == AZH_DTYPE_F32) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        *reinterpret_cast<float *>(out + G::ch_off(cell, ch + i)) = v[i] > 0.0f ? v[i] : 0.0f;
+                        *reinterpret_cast<float *>(lds + G::ch_off(G::real_slot(out_img, cell), ch + i)) = v[i] > 0.0f ? v[i] : 0.0f;
                 } else {
                     typedef typename Tr::pair pair;
-                    const int off = G::ch_off(cell, ch);
+                    const int off = G::ch_off(G::real_slot(out_img, cell), ch);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                         v[i] = v[i] > 0.0f ? v[i] : 0.0f;
@@ -377,7 +379,7 @@ __device__ inline void conv_layer(const unsigned char *lds, int in_off, unsigned
                     uint2 packed;
                     packed.x = __builtin_bit_cast(unsigned, plo);
                     packed.y = __builtin_bit_cast(unsigned, phi);
-                    *reinterpret_cast<uint2 *>(out + off) = packed;
+                    *reinterpret_cast<uint2 *>(lds + off) = packed;
                 }
             }
         }
@@ -399,8 +401,6 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
         return;
     const int nb = (n - tile0) < G::BOARDS ? (n - tile0) : G::BOARDS;
 
-    unsigned char *buf0 = smem;
-    unsigned char *buf1 = smem + G::IMG;
     float *vcell = reinterpret_cast<float *>(smem + G::VCELL_OFF);
     // diagnostic stamps (STAMP builds only): 4 per layer {loop start, loop end, epilogue end, barrier passed}
     unsigned long long *st = nullptr;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     }
 
     // zero both images (zero slots, pad channels of the input planes, unused boards)
-    for (int i = tid * 16; i < 2 * G::IMG; i += NTHREADS * 16)
+    for (int i = tid * 16; i < G::VCELL_OFF; i += NTHREADS * 16)
         *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
@@ -425,17 +425,17 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
         const float f1 = (float)((mover >> sq) & 1ULL), f2 = (float)((opp >> sq) & 1ULL);
         const float f3 = (float)((A.blockers >> sq) & 1ULL);
         if constexpr (DT == AZH_DTYPE_F32) {
-            *reinterpret_cast<float *>(buf0 + G::ch_off(cell, 0)) = 1.0f;
-            *reinterpret_cast<float *>(buf0 + G::ch_off(cell, 1)) = f1;
-            *reinterpret_cast<float *>(buf0 + G::ch_off(cell, 2)) = f2;
-            *reinterpret_cast<float *>(buf0 + G::ch_off(cell, 3)) = f3;
+            *reinterpret_cast<float *>(smem + G::ch_off(G::real_slot(0, cell), 0)) = 1.0f;
+            *reinterpret_cast<float *>(smem + G::ch_off(G::real_slot(0, cell), 1)) = f1;
+            *reinterpret_cast<float *>(smem + G::ch_off(G::real_slot(0, cell), 2)) = f2;
+            *reinterpret_cast<float *>(smem + G::ch_off(G::real_slot(0, cell), 3)) = f3;
         } else {
             typename Tr::quad o;
             o[0] = (typename Tr::elem)1.0f;
             o[1] = (typename Tr::elem)f1;
             o[2] = (typename Tr::elem)f2;
             o[3] = (typename Tr::elem)f3;
-            *reinterpret_cast<typename Tr::quad *>(buf0 + G::ch_off(cell, 0)) = o;
+            *reinterpret_cast<typename Tr::quad *>(smem + G::ch_off(G::real_slot(0, cell), 0)) = o;
         }
     }
 
@@ -481,18 +481,18 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     }
     if constexpr (STAMP) st[1] = stamp_now();
     // (the shift table has one spare row so the last layer's look-ahead stays in bounds)
-    conv_layer<DT, NB, G::KSTEPS_IN, STAMP>(smem, 0, buf1, nullptr, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
+    conv_layer<DT, NB, G::KSTEPS_IN, STAMP>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
     __syncthreads();
     if constexpr (STAMP) st[7] = stamp_now();
     wp += l0;
     for (int b = 0; b < A.blocks; b++) {
         const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP>(smem, G::IMG, buf0, nullptr, wp, aring, sh, t1 + F, vmask, wave, lane,
+        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, wave, lane,
                                                   st + 8 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
         wp += lf;
-        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP>(smem, 0, buf1, buf1, wp, aring, sh, t1 + 2 * F, vmask, wave, lane,
+        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, wave, lane,
                                                   st + 12 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
@@ -500,30 +500,31 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     }
 
     // heads: one 32-row A tile = 17 policy channels + the value conv channel (row 17);
-    // column tiles are dealt round-robin to the waves; logits are staged in buf0.
+    // column tiles are dealt round-robin to the waves; logits go from the accumulators to HBM.
     {
         const afrag *hp = reinterpret_cast<const afrag *>(A.head_w) + lane;
         const int r = lane & 31, h = lane >> 5;
-        float *stage = reinterpret_cast<float *>(buf0);
         for (int ct = wave; ct < G::NT; ct += OCT) {
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; i++)
                 acc[i] = 0.0f;
             const int cell = ct * 32 + r;
-            const int slot = cell < G::NC ? cell : G::zero_slot(cell);
+            const int slot = cell < G::NC ? G::real_slot(1, cell) : G::zero_slot(1, cell);
             for (int ks = 0; ks < G::KSTEPS_FULL; ks++) {
                 const afrag a = hp[(size_t)ks * 64];
-                const afrag bfrag = *reinterpret_cast<const afrag *>(buf1 + G::off(slot, 2 * ks + h));
+                const afrag bfrag = *reinterpret_cast<const afrag *>(smem + G::off(slot, 2 * ks + h));
                 acc = Tr::mfma(a, bfrag, acc);
             }
-            if (cell < G::NC) {
+            if (cell < nb * 49) {
                 const int bl = cell / 49, c = cell % 49;
+                const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
+                float *dst = A.logits + (size_t)game * 833 + 17 * c;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const int oc = (i & 3) + 8 * (i >> 2) + 4 * h;
                     if (oc < 17)
-                        stage[bl * 833 + 17 * c + oc] = acc[i];
+                        dst[oc] = acc[i];
                     else if (oc == 17)
                         vcell[cell] = acc[i];
                 }
@@ -531,13 +532,6 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
         }
     }
     __syncthreads();
-    for (int bl = 0; bl < nb; bl++) {
-        const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
-        const float *src = reinterpret_cast<const float *>(buf0) + bl * 833;
-        float *dst = A.logits + (size_t)game * 833;
-        for (int k = tid; k < 833; k += NTHREADS)
-            dst[k] = src[k];
-    }
     if (tid < nb) {
         const int game = A.list ? A.list[tile0 + tid] : (tile0 + tid);
         float s = 0.0f;
