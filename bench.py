@@ -37,6 +37,19 @@ def tree_bytes(d, logit_bytes=4):
             834 * logit_bytes * d["nn_evals"])
 
 
+def measured_traffic():
+    """HBM bytes per tower launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE, doubled as
+    MI355X_MICROARCH.md §HBM prescribes for gfx950, + WRITE_SIZE), as summarised by tools/prof_bench.sh into
+    profiles/.  PMC counters cannot be read from inside the process, so this is the committed measurement, or null."""
+    import re
+    path = os.path.join(ROOT, "profiles", "round1_bench_pmc_k_tower.txt")
+    try:
+        m = re.search(r"x2 corrected: ([0-9.e+]+) MB\), WRITE_SIZE [0-9.e+]+ KiB \(([0-9.e+]+) MB\)", open(path).read())
+        return (float(m.group(1)) + float(m.group(2))) * 1e6, os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(conv, bn, visits, seconds=15.0, games=128):
     """The oracle port (sequential PUCT per game + numpy f32 net) on the host cores, on a
     bounded sample of the same workload: `games` concurrent games at the same sims/move."""
@@ -138,6 +151,7 @@ def main():
         net_s = tm["net_ms"] * 1e-3
         achieved_tf = d["nn_evals"] * frac_timed * flops / net_s / 1e12 if net_s > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        traffic, traffic_src = measured_traffic()
         tree_s = (tm["select_ms"] + tm["backup_ms"]) * 1e-3
         tree_gbs = tree_bytes(d) * frac_timed / tree_s / 1e9 if tree_s > 0 else 0.0
         out = {
@@ -160,7 +174,7 @@ def main():
             "games_per_s": (plies_total / t_max) / 140.06,
             "games_finished_in_timed_region": games_total,
             "roofline": {"bound": "mfma", "kernel": "k_tower<%s>" % args.dtype, "achieved": achieved_tf, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": tm["net_ms"] / it, "evals_per_launch": d["nn_evals"] / float(args.steps * args.streams),
                          "flops_per_eval": flops},
             "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup+advance+select, fused) + k_compact",
