@@ -126,6 +126,8 @@ template <int DT, int NB> struct Geo {
 struct TowerArgs {
     const void *conv_w;      // packed A fragments, all tower layers back to back
     const void *head_w;      // packed A fragments of the fused policy+value 1x1 conv
+    const void *conv_w2;     // variant 2 packing (16x16x32 fragments)
+    const void *head_w2;
     const float *shift;      // [2B+1][128]  -mean/sqrt(var+eps); the scale 1/sqrt(var+eps) is folded into the packed weights
     const float *fc_w;       // [49]
     float fc_b;
@@ -542,6 +544,327 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     if constexpr (STAMP) st[2] = stamp_now();
 }
 
+// ------------------------------------------------------------------ variant 2 (16-bit types)
+// v_mfma_f32_16x16x32: each wave owns 64 output channels (four 16-channel A tiles) x five 16-cell
+// B tiles, so one B fragment feeds four MFMAs: half the LDS read bytes per FLOP of variant 1,
+// the same accumulator count (4 x 5 x 4 = 80 registers) and the same HBM/L2 traffic.  Waves
+// 0/1 take channels 0-63, waves 2/3 channels 64-127; even waves take cell tiles 0-4, odd 5-9.
+// A fragment: lane l holds W[oc = 16T + (l & 15)][k = 8 (l >> 4) + j]; B fragment: lane l holds
+// act[cell = 16t + (l & 15)][k = 8 (l >> 4) + j]; D: lane l holds oc = 4 (l >> 4) + reg of cell l & 15.
+template <int DT> struct Mfma16;
+template <> struct Mfma16<AZH_DTYPE_BF16> {
+    __device__ static f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<AZH_DTYPE_F16> {
+    __device__ static f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+struct Geo2 {
+    static constexpr int BOARDS = 3;
+    static constexpr int NC = 147;
+    static constexpr int NT = 10;                 // 16-cell tiles (160 >= 147)
+    static constexpr int TPW = 5;                 // cell tiles per wave
+    static constexpr int Z = 16;
+    static constexpr int NSLOT = 320;             // 2*147 + 16 = 310 slots, padded so the unit stride is a
+                                                  // multiple of the 256-B bank row (the four k-groups of a
+                                                  // B-fragment read sit in four consecutive units)
+    static constexpr int UB = 16;
+    static constexpr int NUNIT = 16;
+    static constexpr int CS = NSLOT * UB;         // 5120
+    static constexpr int LDS_BYTES = NUNIT * CS;  // 81,920: two workgroups per CU
+    static constexpr int KS_FULL = F / 32, KS_IN = 1;
+    __device__ static int real_slot(int img, int c) { return img * (NC + Z) + c; }
+    __device__ static int zero_slot(int img, int c) { return NC + ((img * NC + c - NC) & (Z - 1)); }
+    __device__ static int ch_off(int slot, int ch) { return (ch >> 3) * CS + slot * UB + ((ch & 7) << 1); }
+    // value-cell scratch lives in the 10 pad slots of units 0..3
+    __device__ static int vcell_off(int c) { return (c / 40) * CS + 310 * UB + (c % 40) * 4; }
+};
+
+template <int DT, int KS, bool STAMP>
+__device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, bool skip,
+                                   const typename Traits<DT>::afrag *__restrict__ wp,
+                                   typename Traits<DT>::afrag (&a)[2][4], f32x16 &sh, const float *__restrict__ shift_next,
+                                   const int (&vmask)[Geo2::TPW], int wave, int lane, unsigned long long *st)
+{
+    typedef Traits<DT> Tr;
+    typedef Geo2 G;
+    typedef typename Tr::afrag afrag;
+    constexpr int TPW = G::TPW;
+    constexpr int TOTAL = 9 * KS;
+    const int r = lane & 15, kg = lane >> 4;
+    const int oh = wave >> 1, chf = wave & 1;
+    // accumulators [A tile][cell tile], started at the batch-norm shift (+ residual input)
+    f32x4 acc[4][TPW];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        f32x4 init;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            init[i] = sh[4 * t + i];
+#pragma unroll
+        for (int ct = 0; ct < TPW; ct++)
+            acc[t][ct] = init;
+    }
+    if (skip) {
+        typename Tr::quad sk[4][TPW];
+#pragma unroll
+        for (int ct = 0; ct < TPW; ct++) {
+            const int cell = 16 * (TPW * chf + ct) + r;
+            const int slot = cell < G::NC ? G::real_slot(out_img, cell) : G::zero_slot(out_img, cell);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                sk[t][ct] = *reinterpret_cast<const typename Tr::quad *>(lds + G::ch_off(slot, 64 * oh + 16 * t + 4 * kg));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int ct = 0; ct < TPW; ct++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc[t][ct][i] += (float)sk[t][ct][i];
+    }
+    auto fetch_shift = [&]() {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift_next + 64 * oh + 16 * t + 4 * kg);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                sh[4 * t + i] = t4[i];
+        }
+    };
+
+    // A fragments of step s: [s][oc tile 8][lane][8 elements]; this wave reads tiles 4*oh .. 4*oh+3
+    const char *wbase = reinterpret_cast<const char *>(wp) + oh * 4096;
+    const unsigned lane_off = (unsigned)(lane * sizeof(afrag));
+    auto load_a = [&](afrag (&dst)[4], int step) {
+        const char *p = wbase + (size_t)step * 8192;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            dst[t] = *reinterpret_cast<const afrag *>(p + t * 1024 + lane_off);
+    };
+    auto rows_for = [&](int tap, int (&dst)[TPW]) {
+        const int drow = (tap / 3 - 1) * 7 + (tap % 3 - 1);
+#pragma unroll
+        for (int ct = 0; ct < TPW; ct++) {
+            const int c = 16 * (TPW * chf + ct) + r + drow;
+            const int slot = ((vmask[ct] >> tap) & 1) ? G::real_slot(in_img, c) : G::zero_slot(in_img, c);
+            dst[ct] = kg * G::CS + slot * G::UB;
+        }
+    };
+    auto load_b = [&](afrag (&bf)[TPW], const int (&rows)[TPW], int ks) {
+#pragma unroll
+        for (int ct = 0; ct < TPW; ct++)
+            bf[ct] = *reinterpret_cast<const afrag *>(lds + rows[ct] + ks * (4 * G::CS));
+    };
+    afrag b[2][TPW];
+    int cur[TPW], nxt[TPW];
+    auto one_step = [&](auto par_tag, const int (&src)[TPW], int ks_target, int s) {
+        constexpr int par = decltype(par_tag)::value;
+        load_b(b[par ^ 1], src, ks_target);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int ct = 0; ct < TPW; ct++)
+                acc[t][ct] = Mfma16<DT>::mfma(a[par][t], b[par][ct], acc[t][ct]);
+        load_a(a[par], s + 2);
+    };
+    rows_for(0, cur);
+    load_b(b[0], cur, 0);
+    if constexpr (STAMP) st[0] = stamp_now();
+    if constexpr (TOTAL <= 18) {
+        static_for<0, TOTAL>([&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value, t1 = s + 1;
+            constexpr int tap_t = t1 / KS < 9 ? t1 / KS : 8;
+            rows_for(tap_t, cur);
+            one_step(IC<(s & 1)>(), cur, t1 % KS, s);
+        });
+    } else {
+        static_assert(KS % 2 == 0, "pipeline shape");
+        for (int tap = 0; tap < 9; tap++) {
+            rows_for(tap < 8 ? tap + 1 : 8, nxt);
+            static_for<0, KS>([&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+                if constexpr (j + 1 < KS)
+                    one_step(IC<(j & 1)>(), cur, j + 1, tap * KS + j);
+                else
+                    one_step(IC<(j & 1)>(), nxt, 0, tap * KS + j);
+            });
+#pragma unroll
+            for (int ct = 0; ct < TPW; ct++)
+                cur[ct] = nxt[ct];
+        }
+    }
+    if constexpr (STAMP) st[1] = stamp_now();
+    fetch_shift();
+    if constexpr (TOTAL % 2 != 0) {  // ring slots hold steps TOTAL, TOTAL+1 in swapped order
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const afrag tmp = a[0][t];
+            a[0][t] = a[1][t];
+            a[1][t] = tmp;
+        }
+    }
+    // epilogue: relu, convert, write 4 channels (8 bytes) per (A tile, cell tile)
+#pragma unroll
+    for (int ct = 0; ct < TPW; ct++) {
+        const int cell = 16 * (TPW * chf + ct) + r;
+        if (cell < G::NC) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    v[i] = acc[t][ct][i];
+                    v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                }
+                f32x2 lo, hi;
+                lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
+                typedef typename Tr::pair pair;
+                const pair plo = __builtin_convertvector(lo, pair), phi = __builtin_convertvector(hi, pair);
+                uint2 packed;
+                packed.x = __builtin_bit_cast(unsigned, plo);
+                packed.y = __builtin_bit_cast(unsigned, phi);
+                *reinterpret_cast<uint2 *>(lds + G::ch_off(G::real_slot(out_img, cell), 64 * oh + 16 * t + 4 * kg)) = packed;
+            }
+        }
+    }
+    if constexpr (STAMP) st[2] = stamp_now();
+}
+
+template <int DT, bool STAMP = false>
+__global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
+{
+    typedef Traits<DT> Tr;
+    typedef Geo2 G;
+    typedef typename Tr::afrag afrag;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = A.count ? *A.count : A.n;
+    const int tile0 = blockIdx.x * G::BOARDS;
+    if (tile0 >= n)
+        return;
+    const int nb = (n - tile0) < G::BOARDS ? (n - tile0) : G::BOARDS;
+    unsigned long long *st = nullptr;
+    if constexpr (STAMP) {
+        st = A.stamps + ((size_t)blockIdx.x * OCT + wave) * 128;
+        st[0] = stamp_now();
+    }
+    for (int i = tid * 16; i < G::LDS_BYTES; i += NTHREADS * 16)
+        *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int cell = tid; cell < nb * 49; cell += NTHREADS) {
+        const int bl = cell / 49, c = cell % 49;
+        const int x = c / 7, y = c % 7;
+        const int sq = x + 7 * (6 - y);
+        const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
+        const unsigned long long mover = A.boards[2 * (size_t)game + 0];
+        const unsigned long long opp = A.boards[2 * (size_t)game + 1];
+        typename Tr::quad o;
+        o[0] = (typename Tr::elem)1.0f;
+        o[1] = (typename Tr::elem)(float)((mover >> sq) & 1ULL);
+        o[2] = (typename Tr::elem)(float)((opp >> sq) & 1ULL);
+        o[3] = (typename Tr::elem)(float)((A.blockers >> sq) & 1ULL);
+        *reinterpret_cast<typename Tr::quad *>(smem + G::ch_off(G::real_slot(0, cell), 0)) = o;
+    }
+    int vmask[G::TPW];
+    {
+        const int r = lane & 15, chf = wave & 1;
+#pragma unroll
+        for (int ct = 0; ct < G::TPW; ct++) {
+            const int cell = 16 * (G::TPW * chf + ct) + r;
+            int m = 0;
+            if (cell < G::NC) {
+                const int c = cell % 49, x = c / 7, y = c % 7;
+                for (int tap = 0; tap < 9; tap++) {
+                    const int xx = x + tap / 3 - 1, yy = y + tap % 3 - 1;
+                    if (xx >= 0 && xx < 7 && yy >= 0 && yy < 7)
+                        m |= 1 << tap;
+                }
+            }
+            vmask[ct] = m;
+        }
+    }
+    __syncthreads();
+
+    const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w2);
+    const size_t l0 = (size_t)9 * G::KS_IN * 8 * 64, lf = (size_t)9 * G::KS_FULL * 8 * 64;
+    const int oh = wave >> 1, kg = lane >> 4;
+    afrag aring[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            aring[i][t] = wp[((size_t)i * 8 + 4 * oh + t) * 64 + lane];
+    f32x16 sh;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(A.shift + 64 * oh + 16 * t + 4 * kg);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            sh[4 * t + i] = t4[i];
+    }
+    if constexpr (STAMP) st[1] = stamp_now();
+    conv_layer2<DT, G::KS_IN, STAMP>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
+    __syncthreads();
+    if constexpr (STAMP) st[7] = stamp_now();
+    wp += l0;
+    for (int b = 0; b < A.blocks; b++) {
+        const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
+        conv_layer2<DT, G::KS_FULL, STAMP>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, wave, lane, st + 8 + 8 * b);
+        __syncthreads();
+        if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
+        wp += lf;
+        conv_layer2<DT, G::KS_FULL, STAMP>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, wave, lane, st + 12 + 8 * b);
+        __syncthreads();
+        if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
+        wp += lf;
+    }
+    // heads: two 16-row A tiles (policy 0-15 | policy 16, value conv, pad); cell tiles dealt to the waves
+    {
+        const afrag *hp = reinterpret_cast<const afrag *>(A.head_w2) + lane;
+        const int r = lane & 15;
+        for (int ct = wave; ct < G::NT; ct += OCT) {
+            f32x4 acc2[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc2[t][i] = 0.0f;
+            const int cell = 16 * ct + r;
+            const int slot = cell < G::NC ? G::real_slot(1, cell) : G::zero_slot(1, cell);
+#pragma unroll
+            for (int ks = 0; ks < G::KS_FULL; ks++) {
+                const afrag bfrag = *reinterpret_cast<const afrag *>(smem + (4 * ks + kg) * G::CS + slot * G::UB);
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+                    acc2[t] = Mfma16<DT>::mfma(hp[(size_t)(ks * 2 + t) * 64], bfrag, acc2[t]);
+            }
+            if (cell < nb * 49) {
+                const int bl = cell / 49, c = cell % 49;
+                const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
+                float *dst = A.logits + (size_t)game * 833 + 17 * c;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    dst[4 * kg + i] = acc2[0][i];
+                if (kg == 0) {
+                    dst[16] = acc2[1][0];
+                    *reinterpret_cast<float *>(smem + G::vcell_off(cell)) = acc2[1][1];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < nb) {
+        const int game = A.list ? A.list[tile0 + tid] : (tile0 + tid);
+        float s = 0.0f;
+        for (int c = 0; c < 49; c++)
+            s = __builtin_fmaf(*reinterpret_cast<const float *>(smem + G::vcell_off(tid * 49 + c)), A.fc_w[c], s);
+        A.values[game] = tanhf(s + A.fc_b);
+    }
+    if constexpr (STAMP) st[2] = stamp_now();
+}
+
 // ------------------------------------------------------------------ host side
 
 static inline uint16_t f32_to_bf16(float f)
@@ -587,9 +910,29 @@ static void pack_conv(const float *w, const float *scale, int cin, int taps, int
                     }
 }
 
+// Variant 2 packing: [tap][ks (32 channels)][oc tile 16 x ntiles][lane][8]: lane l holds
+// W[c = 32 ks + 8 (l >> 4) + e][oc = 16 T + (l & 15)].
+static void pack_conv16(const float *w, const float *scale, int cin, int taps, int ksteps, int ntiles, int ocols, int dt,
+                        std::vector<uint16_t> &out)
+{
+    for (int tap = 0; tap < taps; tap++)
+        for (int ks = 0; ks < ksteps; ks++)
+            for (int T = 0; T < ntiles; T++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 8; e++) {
+                        const int c = 32 * ks + 8 * (lane >> 4) + e, oc = 16 * T + (lane & 15);
+                        float v = 0.0f;
+                        if (c < cin && oc < ocols)
+                            v = w[((size_t)tap * cin + c) * ocols + oc] * (scale ? scale[oc] : 1.0f);
+                        out.push_back(cvt_elem<uint16_t>(v, dt));
+                    }
+}
+
 struct NetDtypeBuffers {
     void *conv_w = nullptr;
     void *head_w = nullptr;
+    void *conv_w2 = nullptr;
+    void *head_w2 = nullptr;
 };
 
 }  // namespace azh
@@ -649,6 +992,15 @@ static int net_pack(azh_net *net, int dt)
         pack_conv<uint16_t>(head.data(), nullptr, F, 1, ks_full, kstep, 1, 32, dt, hw);
         if (upload(cw.data(), cw.size() * 2, &net->bufs[dt].conv_w)) return -1;
         if (upload(hw.data(), hw.size() * 2, &net->bufs[dt].head_w)) return -1;
+        // variant 2
+        std::vector<uint16_t> cw2, hw2;
+        pack_conv16(p, sc, 4, 9, 1, 8, F, dt, cw2);
+        for (int l = 0; l < 2 * B; l++)
+            pack_conv16(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, sc + (size_t)(l + 1) * F, F, 9, 4, 8, F, dt, cw2);
+        cw2.resize(cw2.size() + (size_t)2 * 8 * 64 * 8, 0);  // the A ring reads two steps past the last layer
+        pack_conv16(head.data(), nullptr, F, 1, 4, 2, 32, dt, hw2);
+        if (upload(cw2.data(), cw2.size() * 2, &net->bufs[dt].conv_w2)) return -1;
+        if (upload(hw2.data(), hw2.size() * 2, &net->bufs[dt].head_w2)) return -1;
     }
     return 0;
 }
@@ -696,6 +1048,8 @@ extern "C" void azh_net_destroy(azh_net *net)
     for (auto &b : net->bufs) {
         if (b.conv_w) (void)hipFree(b.conv_w);
         if (b.head_w) (void)hipFree(b.head_w);
+        if (b.conv_w2) (void)hipFree(b.conv_w2);
+        if (b.head_w2) (void)hipFree(b.head_w2);
     }
     if (net->d_shift) (void)hipFree(net->d_shift);
     if (net->d_fcw) (void)hipFree(net->d_fcw);
@@ -722,6 +1076,34 @@ static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
 
 // Boards per workgroup for the 16-bit towers: 3 (two workgroups per CU) unless
 // AZH_TOWER_BOARDS=6 asks for one 6-board workgroup per CU.
+template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &args, int max_n, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        AZH_HIP(hipFuncSetAttribute((const void *)k_tower2<DT, STAMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Geo2::LDS_BYTES));
+        attr_set = true;
+    }
+    const int grid = (max_n + Geo2::BOARDS - 1) / Geo2::BOARDS;
+    if (grid <= 0)
+        return 0;
+    hipLaunchKernelGGL((k_tower2<DT, STAMP>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args);
+    AZH_HIP(hipGetLastError());
+    return 0;
+}
+
+// The 16-bit towers run variant 2 (16x16x32 MFMA, 64 channels per wave); AZH_TOWER=1 selects
+// variant 1 (32x32x16, 32 channels per wave), which is also the f32 tower's shape.
+static int tower_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("AZH_TOWER");
+        v = (e && atoi(e) == 1) ? 1 : 2;
+    }
+    return v;
+}
+
 static int tower_boards()
 {
     static int v = -1;
@@ -745,6 +1127,8 @@ int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, 
     TowerArgs a;
     a.conv_w = net->bufs[dtype].conv_w;
     a.head_w = net->bufs[dtype].head_w;
+    a.conv_w2 = net->bufs[dtype].conv_w2;
+    a.head_w2 = net->bufs[dtype].head_w2;
     a.shift = net->d_shift;
     a.fc_w = net->d_fcw;
     a.fc_b = net->fc_b;
@@ -758,6 +1142,13 @@ int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, 
     a.values = d_values;
     a.stamps = d_stamps;
     const bool six = tower_boards() == 6;
+    if (tower_variant() == 2 && dtype != AZH_DTYPE_F32) {
+        if (d_stamps)
+            return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16, true>(a, max_n, stream)
+                                           : azh_fail(-2, "stamps are built for bf16 only");
+        return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16>(a, max_n, stream)
+                                       : launch_tower2<AZH_DTYPE_F16>(a, max_n, stream);
+    }
     if (d_stamps) {  // diagnostic instantiations (bf16 only)
         if (dtype != AZH_DTYPE_BF16)
             return azh_fail(-2, "stamps are built for bf16 only");
