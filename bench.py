@@ -173,7 +173,7 @@ def main():
             # over 11,601 games written by the real CLI in a 240 s soak of this workload
             "games_per_s": (plies_total / t_max) / 140.06,
             "games_finished_in_timed_region": games_total,
-            "roofline": {"bound": "mfma", "kernel": "k_tower<%s>" % args.dtype, "achieved": achieved_tf, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "%s<%s>" % ("k_tower" if args.dtype == "f32" or os.environ.get("AZH_TOWER") == "1" else "k_tower2", args.dtype), "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": tm["net_ms"] / it, "evals_per_launch": d["nn_evals"] / float(args.steps * args.streams),
                          "flops_per_eval": flops},

@@ -15,7 +15,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc4 -- python3 $R/bench.
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc5 -- python3 $R/bench.py $ARGS > $OUT/pmc5.log 2>&1 || exit 6
 # keep the merge small: the per-dispatch counter CSVs are large; summarise on the box
 python3 $R/tools/prof_summary.py $OUT k_tower > $OUT/summary_k_tower.txt 2>&1
-for k in k_select k_backup k_advance k_compact; do python3 $R/tools/prof_summary.py $OUT $k > $OUT/summary_$k.txt 2>&1; done
+for k in k_tree k_select k_compact; do python3 $R/tools/prof_summary.py $OUT $k > $OUT/summary_$k.txt 2>&1; done
 find $OUT -name "*_counter_collection.csv" -delete
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete
 ls -la $OUT
