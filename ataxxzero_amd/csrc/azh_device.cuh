@@ -374,6 +374,7 @@ __host__ __device__ inline Philox4 philox(u32 k0, u32 k1, u32 c0, u32 c1, u32 c2
 
 constexpr u32 STREAM_SAMPLE = 1u;
 constexpr u32 STREAM_RANDOM_PLAY = 2u;
+constexpr u32 STREAM_RANDOM_PLY = 3u;
 constexpr u32 STREAM_GAMMA = 0x10000u;
 
 // Gamma(alpha, 1), alpha < 1: Marsaglia-Tsang on alpha + 1 with a polar normal,

@@ -100,6 +100,14 @@ __device__ inline Arena arena_of(const EngineParams &P, int a, int g)
     return A;
 }
 
+// ONE_RANDOM_MOVE (:515-518): ply of the uniformly random move, uniform on 0..119, a pure function of
+// (seed, game uid).
+__device__ inline int random_ply_of(const EngineParams &P, u32 uid)
+{
+    const Philox4 r = philox(P.k0, P.k1, uid, 0u, STREAM_RANDOM_PLY, 0u);
+    return (int)(((u64)r.v[0] * 120ull) >> 32);
+}
+
 __device__ inline void add_stat(const EngineParams &P, int g, int k, u64 v)
 {
     if (v)
@@ -580,6 +588,26 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     }
     if (chosen < 0)
         chosen = 0;
+    if (P.flags & AZH_FLAG_ONE_RANDOM_MOVE) {
+        const int rp = random_ply_of(P, s.uid);
+        if (s.ply == rp) {
+            // AT the randomization point: a uniformly random legal move (:531-540)
+            chosen = (int)(((u64)rr.v[1] * (u64)(u32)M) >> 32);
+        } else if (s.ply > rp) {
+            // AFTER it: the most visited move (:543-551), first maximum in movegen order
+            u64 key = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = lane + 64 * k;
+                if (j < M) {
+                    const u64 kk = ((u64)ev[k].y << 32) | (u64)(0xFFFFFFFFu - (u32)j);
+                    key = kk > key ? kk : key;
+                }
+            }
+            key = wave_max_u64(key);
+            chosen = (int)(0xFFFFFFFFu - (u32)key);
+        }
+    }
 
     // record the ply (:565-572): board, move, visit distribution over expanded edges
     u32 *rec = P.rec + ((size_t)g * P.max_plies + s.ply) * REC_STRIDE_WORDS;
@@ -747,7 +775,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
                 out[3] = (u32)s.ply;
                 out[4] = (u32)result;
                 out[5] = (u32)words;
-                out[6] = 0;
+                out[6] = (P.flags & AZH_FLAG_ONE_RANDOM_MOVE) ? (u32)random_ply_of(P, s.uid) + 1u : 0u;
                 out[7] = 0;
             }
             u32 pos = 8;

@@ -33,7 +33,7 @@ static void append_double(double v, std::string &out)
 }
 
 // rec: ring record (engine.hip k_advance): 8-word header {magic, slot, uid, plies,
-// result, words, 0, 0} then per ply {x lo, x hi, o lo, o hi, move | nd << 16, 0,
+// result, words, random_ply + 1 (0 = none), 0} then per ply {x lo, x hi, o lo, o hi, move | nd << 16, 0,
 // nd x (move | visits << 16)}.
 // with_ids (arena): two extra keys, "slot" and "uid", so the caller can tell which net had x.
 std::string azh_format_game_json(const uint32_t *rec, size_t words, bool with_ids)
@@ -85,6 +85,8 @@ std::string azh_format_game_json(const uint32_t *rec, size_t words, bool with_id
         pos += 6 + nd;
     }
     std::string out = "{\"boards\":" + boards + "],\"dists\":" + dists + "],\"moves\":" + moves + "],\"result\":";
+    if (rec[6])  // ONE_RANDOM_MOVE games (cpp/self_play_client.cpp:517); keys stay sorted as nlohmann emits them
+        out = out.substr(0, out.size() - 9) + "\"random_ply\":" + std::to_string(rec[6] - 1) + ",\"result\":";
     out += std::to_string(result);
     if (with_ids)
         out += ",\"slot\":" + std::to_string(rec[1]) + ",\"uid\":" + std::to_string(rec[2]);

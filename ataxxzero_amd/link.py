@@ -25,6 +25,7 @@ DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTY
 LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
 FLAG_NO_REUSE, FLAG_TIE_FIRST, FLAG_PY_POSTERIOR, FLAG_SAMPLE_POW5, FLAG_KEEP_UNFINISHED, FLAG_TWO_NETS = 1, 2, 4, 8, 16, 32
 FLAG_ARENA = 63
+FLAG_ONE_RANDOM_MOVE = 64  # cpp/self_play_client.cpp:515-552 (compile-time variant of the reference client)
 STAT_NAMES = ["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
               "edge_overflow", "reroot_nodes", "reroot_edges", "ring_overflow"]
 

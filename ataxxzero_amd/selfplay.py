@@ -136,6 +136,8 @@ class SelfPlay:
 def python_move(mv):
     """u16 move -> the Python generator's move value (generate_games.py:51 stores the
     ataxx_rules tuple; json turns it into nested lists): ["c",[x,y]] / [[x0,y0],[x1,y1]]."""
+    if mv == 0xFFFF:
+        return "pass"
     frm, to = mv & 0xFF, mv >> 8
     end = [to % 7, 6 - to // 7]
     if frm == to:

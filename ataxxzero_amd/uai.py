@@ -58,6 +58,22 @@ class Position:
         x, o, bl, turn = selfplay.parse_fen(fen)
         return Position(x, o, turn)
 
+    def fen(self):
+        """FEN in the reference's dialect (ataxx_rules.py fen(): ranks 7..1, x/o/digits, side to move)."""
+        rows = []
+        for r in range(6, -1, -1):
+            row, run = "", 0
+            for f in range(7):
+                bit = 1 << (f + 7 * r)
+                ch = "x" if self.x & bit else ("o" if self.o & bit else None)
+                if ch is None:
+                    run += 1
+                else:
+                    row += (str(run) if run else "") + ch
+                    run = 0
+            rows.append(row + (str(run) if run else ""))
+        return "/".join(rows) + (" x" if self.turn == 0 else " o")
+
     def packed(self):
         return link.pack_board(self.x, self.o, self.turn)
 

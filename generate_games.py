@@ -1,13 +1,14 @@
 #!/usr/bin/python
-"""Drop-in for the reference's generate_games.py on the path BASELINE.json scopes:
-`--random-play` bootstrap games (generate_games.py:16-75, :127-140), played by a HIP
-playout kernel instead of the pure-Python rules.  Same flags, same entry format
-({"boards", "moves", "result"}, json.dump default separators, one game per line).
+"""Drop-in for the reference's generate_games.py (generate_games.py:16-75, :127-140).  Same flags,
+same entry format ({"boards", "moves", "result"}, json.dump default separators, one game per line).
 
-The reference's other modes are outside the hot path (Python-MCTS self-play is broken in
-the reference itself — generate_games.py:43 calls a function that does not exist — and
-`--supervised` needs an external UAI teacher); use accelerated_generate_games.py for
-network self-play.
+* `--random-play`: bootstrap games, played by a HIP playout kernel instead of the pure-Python rules.
+* `--supervised CMD [--supervised-ms N]`: teacher games — an external UAI engine picks every
+  training move, with the reference's opening randomisation (ataxxzero_amd/supervised.py); rules on the GPU.
+
+The reference's third mode, Python-MCTS self-play, is broken in the reference itself
+(generate_games.py:43 calls a function that does not exist); use accelerated_generate_games.py
+for network self-play.
 """
 import argparse
 import json
@@ -31,15 +32,16 @@ parser.add_argument("--die-if-present", metavar="PATH", default=None, type=str, 
 parser.add_argument("--show-game", action="store_true", help="(reference flag; not supported here)")
 parser.add_argument("--game-count", metavar="N", default=None, type=int, help="Maximum number of games to generate.")
 parser.add_argument("--no-write", action="store_true", help="Don't write out generated games at all.")
-parser.add_argument("--supervised", metavar="CMD", default=None, type=str, help="(reference flag; not supported here)")
-parser.add_argument("--supervised-ms", metavar="N", default=100, type=int, help="(reference flag; not supported here)")
+parser.add_argument("--supervised", metavar="CMD", default=None, type=str, help="Command for a UAI engine.")
+parser.add_argument("--supervised-ms", metavar="N", default=100, type=int, help="Number of milliseconds per move for supervised generation.")
 parser.add_argument("--seed", type=int, default=0, help="Philox seed (extension).")
 args = parser.parse_args()
 
-if not args.random_play or args.use_rpc or args.supervised or args.show_game:
-    raise SystemExit("generate_games.py: only --random-play is provided by the MI355X build; "
+if args.use_rpc or args.show_game or not (args.random_play or args.supervised):
+    raise SystemExit("generate_games.py: --random-play and --supervised are provided by the MI355X build; "
                      "use accelerated_generate_games.py for network self-play.")
-print("Doing random play! Loading no model, and not using RPC.")
+if args.random_play:
+    print("Doing random play! Loading no model, and not using RPC.")
 selfplay.select_device(args.group_index)
 
 output_path = "/dev/null" if args.no_write else args.output_games
@@ -47,6 +49,37 @@ if output_path is None:
     os.makedirs("games", exist_ok=True)
     output_path = os.path.join("games", "random-%s.json" % os.urandom(8).hex())
 print("[%3i] Writing to: %s" % (args.group_index, output_path))
+
+if not args.random_play:
+    import random
+    import shlex
+
+    from ataxxzero_amd import supervised
+    random.seed(args.seed * 1000003 + args.group_index)
+    teacher = supervised.UAIPlayer(shlex.split(args.supervised))
+    try:
+        with open(output_path, "w") as f:
+            games_generated = 0
+            while True:
+                entry = supervised.generate_game(teacher, args.supervised_ms)
+                print("[%3i] Generated a %i ply game with result %r." % (
+                    args.group_index, len(entry["boards"]), entry["result"]))
+                if entry["result"] is None:
+                    print("[%3i] Skipping game with null result." % (args.group_index,))
+                    continue
+                json.dump(entry, f)
+                f.write("\n")
+                f.flush()
+                games_generated += 1
+                if args.game_count is not None and games_generated >= args.game_count:
+                    print("Done generating games.")
+                    break
+                if args.die_if_present and os.path.exists(args.die_if_present):
+                    print("Exiting due to signal file!")
+                    break
+    finally:
+        teacher.quit()
+    raise SystemExit(0)
 
 BATCH = 1024
 with open(output_path, "w") as f:  # the reference truncates here (generate_games.py:127)

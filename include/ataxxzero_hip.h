@@ -141,7 +141,10 @@ enum {
                                      annulled, uai_ringmaster.py:147-150) instead of dropped */
     AZH_FLAG_TWO_NETS = 32,       /* arena: the side to move alternates between two nets; slot parity picks
                                      which net plays x; records carry "slot" and "uid" */
-    AZH_FLAG_ARENA = 1 | 2 | 4 | 8 | 16 | 32
+    AZH_FLAG_ARENA = 1 | 2 | 4 | 8 | 16 | 32,
+    AZH_FLAG_ONE_RANDOM_MOVE = 64 /* the ONE_RANDOM_MOVE build of the client (cpp/self_play_client.cpp:515-552):
+                                     per game one ply in 0..119 plays a uniformly random legal move, every later
+                                     ply the most visited move; the entry gains "random_ply" (train.py:47-49) */
 };
 
 typedef struct {

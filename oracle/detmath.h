@@ -101,6 +101,7 @@ static inline void orc_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1
 
 #define ORC_STREAM_SAMPLE 1u
 #define ORC_STREAM_RANDOM_PLAY 2u
+#define ORC_STREAM_RANDOM_PLY 3u
 #define ORC_STREAM_GAMMA 0x10000u
 
 /* Gamma(alpha, 1) for alpha < 1: Marsaglia-Tsang on alpha + 1 with a polar

@@ -395,6 +395,15 @@ static void backup_path(orc_engine *e, int g, float value)
         s->root_visits += 1;
 }
 
+/* ONE_RANDOM_MOVE (:515-518): the ply of the uniformly random move, uniform on 0..119, a pure
+ * function of (seed, game uid). */
+static int random_ply_of(const orc_engine *e, uint32_t uid)
+{
+    uint32_t r[4];
+    orc_philox((uint32_t)e->cfg.seed, (uint32_t)(e->cfg.seed >> 32), uid, 0, ORC_STREAM_RANDOM_PLY, 0, r);
+    return (int)(((uint64_t)r[0] * 120u) >> 32);
+}
+
 static void finish_game(orc_engine *e, int g, int result)
 {
     orc_game_state *s = &e->gs[g];
@@ -409,6 +418,8 @@ static void finish_game(orc_engine *e, int g, int result)
     b->next = NULL;
     b->size = size;
     int32_t hdr[4] = {g, (int32_t)s->uid, s->ply, result};
+    if (e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE)
+        hdr[3] |= (random_ply_of(e, s->uid) + 1) << 8;
     memcpy(b->data, hdr, 16);
     uint8_t *w = b->data + 16;
     for (int p = 0; p < s->ply; p++) {
@@ -473,6 +484,23 @@ static void advance_game(orc_engine *e, int g)
     }
     if (chosen < 0)
         chosen = 0;
+    if (e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE) {
+        int rp = random_ply_of(e, s->uid);
+        if (s->ply == rp) {
+            /* AT the randomization point: a uniformly random legal move (:531-540) */
+            chosen = (int)(((uint64_t)rnd[1] * (uint32_t)M) >> 32);
+        } else if (s->ply > rp) {
+            /* AFTER it: the most visited move (:543-551); the reference's strict '>' over an
+             * unordered_map leaves ties to hash order: fixed here as the first maximum */
+            uint32_t best = 0;
+            chosen = 0;
+            for (int j = 0; j < M; j++)
+                if (ed[4 * (first + j) + 1] > best) {
+                    best = ed[4 * (first + j) + 1];
+                    chosen = j;
+                }
+        }
+    }
     /* record (:565-572) */
     uint8_t *rec = REC(e, g, s->ply);
     uint64_t bx = nb[0] & ~TURN_BIT, bo = nb[1];

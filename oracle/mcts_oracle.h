@@ -40,7 +40,8 @@ typedef struct {
 
 enum {
     ORC_FLAG_NO_REUSE = 1, ORC_FLAG_TIE_FIRST = 2, ORC_FLAG_PY_POSTERIOR = 4, ORC_FLAG_SAMPLE_POW5 = 8,
-    ORC_FLAG_KEEP_UNFINISHED = 16, ORC_FLAG_TWO_NETS = 32, ORC_FLAG_ARENA = 63
+    ORC_FLAG_KEEP_UNFINISHED = 16, ORC_FLAG_TWO_NETS = 32, ORC_FLAG_ARENA = 63,
+    ORC_FLAG_ONE_RANDOM_MOVE = 64 /* the ONE_RANDOM_MOVE build of the client (cpp/self_play_client.cpp:515-552) */
 };
 
 enum { ORC_LEAF_NONE = 0, ORC_LEAF_EVAL = 1, ORC_LEAF_TERMINAL = 2, ORC_LEAF_ROOT = 3 };
@@ -93,6 +94,7 @@ void orc_engine_stats(const orc_engine *e, uint64_t *out /* ORC_STAT_COUNT */);
 
 /* finished games, oldest first. Record = int32 header {slot, uid, plies, result}
  * then per ply {x u64, o u64, move u16, ndist u16, pad u32, ndist * u32 (move | n << 16)}.
+ * With ORC_FLAG_ONE_RANDOM_MOVE the header's result word carries (random_ply + 1) << 8.
  * Returns bytes written (0 when none pending or cap too small for the next game). */
 int64_t orc_engine_pop_game(orc_engine *e, uint8_t *buf, int64_t cap);
 int orc_engine_pending_games(const orc_engine *e);

@@ -17,6 +17,7 @@ STAT_COUNT = 16
 LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
 FLAG_NO_REUSE, FLAG_TIE_FIRST, FLAG_PY_POSTERIOR, FLAG_SAMPLE_POW5, FLAG_KEEP_UNFINISHED, FLAG_TWO_NETS = 1, 2, 4, 8, 16, 32
 FLAG_ARENA = 63
+FLAG_ONE_RANDOM_MOVE = 64
 
 
 class Pos(ctypes.Structure):
@@ -180,8 +181,10 @@ def parse_game_record(buf):
         moves.append(move_string(mv))
         total = int(sum(int(e) >> 16 for e in ents))
         dists.append({move_string(int(e) & 0xFFFF): (int(e) >> 16) / total for e in ents})
-    return {"slot": slot, "uid": uid & 0xFFFFFFFF,
-            "entry": {"boards": boards, "dists": dists, "moves": moves, "result": res}}
+    entry = {"boards": boards, "dists": dists, "moves": moves, "result": res & 0xFF}
+    if res >> 8:
+        entry["random_ply"] = (res >> 8) - 1
+    return {"slot": slot, "uid": uid & 0xFFFFFFFF, "entry": entry}
 
 
 class Engine:

@@ -222,3 +222,49 @@ def test_uai_interface_engine_plays_legal_moves(tmp_path):
         assert uai_interface.uai_encode_move(uai_interface.uai_decode_move(s)) == s
     for m in [("c", (4, 3)), ((4, 3), (2, 5))]:
         assert uai_interface.uai_decode_move(uai_interface.uai_encode_move(m)) == m
+
+
+def test_generate_games_supervised_with_own_uai_engine_as_teacher(tmp_path):
+    """generate_games.py --supervised CMD (generate_games.py:26-34,45-49): the teacher's move is the
+    training move, the played move may be the opening randomisation's; entries have no dists."""
+    conv, bn = model.random_init(1, 128, seed=13)
+    net = str(tmp_path / "teacher.npy")
+    model.save_model(net, conv, bn)
+    out = str(tmp_path / "supervised.json")
+    teacher = "%s %s --network-path %s --visits 6" % (sys.executable, os.path.join(ROOT, "uai_interface.py"), net)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "generate_games.py"), "--supervised", teacher,
+                          "--supervised-ms", "50", "--output-games", out, "--game-count", "2"],
+                         cwd=ROOT, capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in open(out) if l.strip()]
+    assert len(lines) == 2
+    for line in lines:
+        entry = json.loads(line)
+        assert list(entry) == ["boards", "moves", "result"] and entry["result"] in (1, 2)
+        cells_of = lambda p: [int(v) for v in orc.board_cells(p)]
+        p = orc.pos_from_fen(orc.START_FEN_PLAIN)
+        for i, (b, m) in enumerate(zip(entry["boards"], entry["moves"])):
+            assert cells_of(p) == b, i
+            legal = [int(x) for x in orc.movegen(p)]
+            sq = lambda xy: xy[0] + 7 * (6 - xy[1])
+            mv = sq(m[1]) | (sq(m[1]) << 8) if m[0] == "c" else sq(m[0]) | (sq(m[1]) << 8)
+            assert mv in legal, (i, m)
+            if i + 1 < len(entry["boards"]):
+                # the played move is the teacher's or a random legal one: the next board is a successor
+                nxt = None
+                for c in legal:
+                    q = orc.Pos()
+                    q.pieces[0], q.pieces[1], q.blockers, q.turn, q.ply = p.pieces[0], p.pieces[1], p.blockers, p.turn, p.ply
+                    orc.lib().orc_makemove(q, c & 0xFF, c >> 8)
+                    if cells_of(q) == entry["boards"][i + 1]:
+                        nxt = q
+                        break
+                assert nxt is not None, i
+                p = nxt
+    # train.py consumes such entries through the one-hot branch (train.py:64-65)
+    from ataxxzero_amd import training
+    import random
+    random.seed(1)
+    entries = training.load_entries([out])
+    f, pol, val = training.get_sample_from_entries(entries)
+    assert abs(pol.sum() - 1.0) < 1e-6 and val[0] in (1, -1)

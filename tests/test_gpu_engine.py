@@ -14,9 +14,10 @@ from tests.helpers import replay_game_entry, synthetic_evals
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(games, visits, max_plies=400, edges_per_node=96, seed=77, fen=orc.START_FEN_SELFPLAY, weight=0.25):
+def make_pair(games, visits, max_plies=400, edges_per_node=96, seed=77, fen=orc.START_FEN_SELFPLAY, weight=0.25,
+              flags=0):
     ocfg = orc.make_config(games, visits, seed=seed, fen_str=fen, max_plies=max_plies,
-                           edges_per_node=edges_per_node, weight=weight)
+                           edges_per_node=edges_per_node, weight=weight, flags=flags)
     gcfg = link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_})
     return orc.Engine(ocfg), link.Engine(gcfg)
 
@@ -140,3 +141,20 @@ def test_odd_sizes_and_f16_device_loop():
         st = ge.stats()
         assert st["steps"] > 40 * games and st["plies"] > 5 * games and st["edge_overflow"] == 0
         ge.close()
+
+
+def test_one_random_move_variant_matches_oracle():
+    # cpp/self_play_client.cpp:515-552 (ONE_RANDOM_MOVE build): entries carry "random_ply"
+    oe, ge = make_pair(games=32, visits=8, max_plies=240, seed=11, flags=orc.FLAG_ONE_RANDOM_MOVE)
+    assert link.FLAG_ONE_RANDOM_MOVE == orc.FLAG_ONE_RANDOM_MOVE
+    o_games, g_lines = run_lockstep(oe, ge, 2400, check_every=31)
+    o_sorted = sorted(o_games, key=lambda r: r["uid"])
+    assert len(g_lines) == len(o_sorted) and len(g_lines) >= 4
+    assert any(r["entry"]["random_ply"] + 1 < len(r["entry"]["moves"]) for r in o_sorted)  # all three branches ran
+    canon = lambda en: json.dumps(en, sort_keys=True)
+    # games finish in different iterations, so compare as sets (uids are not part of the line)
+    assert sorted(canon(json.loads(l)) for l in g_lines) == sorted(canon(r["entry"]) for r in o_sorted)
+    for line in g_lines:
+        entry = json.loads(line)
+        assert list(entry.keys()) == ["boards", "dists", "moves", "random_ply", "result"]
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]

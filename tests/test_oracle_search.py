@@ -94,3 +94,27 @@ def test_plies_cap_drops_games():
     games = run(e, 400, synthetic_evals)
     st = e.stats()
     assert st["dropped"] > 0 and all(len(r["entry"]["moves"]) <= 10 for r in games)
+
+
+def test_one_random_move_variant():
+    # ONE_RANDOM_MOVE (cpp/self_play_client.cpp:515-552): random_ply uniform on 0..119; after it
+    # the move played is the most visited one; at it any legal move (replay validates legality)
+    cfg = orc.make_config(games=48, visits=8, seed=3, max_plies=150, flags=orc.FLAG_ONE_RANDOM_MOVE)
+    e = orc.Engine(cfg)
+    games = run(e, 2600, null_eval)
+    assert len(games) >= 20
+    rps = [g["entry"]["random_ply"] for g in games]
+    assert all(0 <= r < 120 for r in rps) and len(set(rps)) > 10
+    after = 0
+    for g in games:
+        en = g["entry"]
+        assert replay_game_entry(en, orc.START_FEN_SELFPLAY) == en["result"]
+        for ply in range(en["random_ply"] + 1, len(en["moves"])):
+            d = en["dists"][ply]
+            assert d[en["moves"][ply]] == max(d.values())
+            after += 1
+    assert after > 50
+    # a different game uid draws a different ply; same seed + uid reproduces it
+    e2 = orc.Engine(cfg)
+    games2 = run(e2, 2600, null_eval)
+    assert [g["entry"] for g in games2] == [g["entry"] for g in games]

@@ -54,8 +54,8 @@ def main(args):
         if line == "quit":
             return
         elif line == "uai":
-            print("id name AtaxxZero")
-            print("id author Peter Schmidt-Nielsen")
+            print("id name AtaxxZero-MI355X")
+            print("id author ataxxzero_amd")
             print("uaiok")
         elif line == "uainewgame":
             board = uai.Position.initial()
