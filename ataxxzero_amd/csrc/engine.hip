@@ -890,6 +890,7 @@ struct azh_engine {
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     float *d_feat = nullptr;
+    float *d_sym_logits = nullptr, *d_sym_values = nullptr;  // AZH_FLAG_SYMMETRY_AVG scratch
     u64 *d_stat_out = nullptr;
     // finished games formatted but not yet handed out
     std::vector<std::string> pending;
@@ -1001,6 +1002,10 @@ extern "C" void azh_engine_destroy(azh_engine *e)
         (void)hipFree(p);
     if (e->d_feat)
         (void)hipFree(e->d_feat);
+    if (e->d_sym_logits)
+        (void)hipFree(e->d_sym_logits);
+    if (e->d_sym_values)
+        (void)hipFree(e->d_sym_values);
     if (e->h_count)
         (void)hipHostFree(e->h_count);
     if (e->stream)
@@ -1075,12 +1080,25 @@ extern "C" int azh_engine_leaf_features(azh_engine *e, float *out, int32_t *game
     return 0;
 }
 
+// one evaluation of the listed leaves by `net`; with AZH_FLAG_SYMMETRY_AVG the 8-way averaged one
+static int launch_eval(azh_engine *e, azh_net *net, int dtype, const int *list, const int *count)
+{
+    if (!(e->P.flags & AZH_FLAG_SYMMETRY_AVG))
+        return azh_net_launch(net, dtype, (const unsigned long long *)e->P.leaf_board, list, count, e->P.G,
+                              e->P.blockers, e->P.logits, e->P.values, e->stream);
+    if (!e->d_sym_logits) {
+        AZH_HIP(hipMalloc((void **)&e->d_sym_logits, (size_t)e->P.G * 8 * AZH_POLICY_SIZE * 4));
+        AZH_HIP(hipMalloc((void **)&e->d_sym_values, (size_t)e->P.G * 8 * 4));
+    }
+    return azh_net_launch_sym(net, dtype, (const unsigned long long *)e->P.leaf_board, list, count, e->P.G,
+                              e->P.blockers, e->d_sym_logits, e->d_sym_values, e->P.logits, e->P.values, e->stream);
+}
+
 extern "C" int azh_engine_eval(azh_engine *e, azh_net *net, int dtype)
 {
     if (!e || !net)
         return azh_fail(-1, "azh_engine_eval: null argument");
-    return azh_net_launch(net, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list, e->P.leaf_count,
-                          e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
+    return launch_eval(e, net, dtype, e->P.leaf_list, e->P.leaf_count);
 }
 
 extern "C" int azh_engine_set_evals(azh_engine *e, const float *logits, const float *values)
@@ -1128,11 +1146,9 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         const bool rec = e->timing && e->ev_used + 4 <= e->events.size();
         hipEvent_t *ev = rec ? &e->events[e->ev_used] : nullptr;
         if (rec) AZH_HIP(hipEventRecord(ev[1], e->stream));
-        int rc = azh_net_launch(net_a, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list, e->P.leaf_count,
-                                e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
+        int rc = launch_eval(e, net_a, dtype, e->P.leaf_list, e->P.leaf_count);
         if (rc == 0 && net_b)
-            rc = azh_net_launch(net_b, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list2,
-                                e->P.leaf_count2, e->P.G, e->P.blockers, e->P.logits, e->P.values, e->stream);
+            rc = launch_eval(e, net_b, dtype, e->P.leaf_list2, e->P.leaf_count2);
         if (rc) return rc;
         if (rec) AZH_HIP(hipEventRecord(ev[2], e->stream));
         const int last = it + 1 == iterations;

@@ -140,7 +140,36 @@ struct TowerArgs {
     float *logits;           // [..][833], indexed by game
     float *values;           // [..], indexed by game
     unsigned long long *stamps;  // diagnostic build only: [workgroup][wave][128] s_memtime stamps
+    int sym;                 // 1: test-time symmetry averaging (nn_evals.py:48-62): virtual board v is list entry
+                             // v >> 3 under dihedral symmetry v & 7; outputs are indexed by v, not by game
 };
+
+// apply_symmetry (nn_evals.py:8-16): cell (x, y) of the transformed tensor shows cell (ox, oy) of the original
+__device__ __host__ inline void sym_cell(int s, int x, int y, int &ox, int &oy)
+{
+    const int a = (s & 4) ? y : x, b = (s & 4) ? x : y;
+    ox = (s & 1) ? 6 - a : a;
+    oy = (s & 2) ? 6 - b : b;
+}
+
+// source game and source square of cell (x, y) of (virtual) board v
+__device__ inline int tower_src(const TowerArgs &A, int v, int x, int y, int &sq)
+{
+    int ox = x, oy = y;
+    if (A.sym)
+        sym_cell(v & 7, x, y, ox, oy);
+    sq = ox + 7 * (6 - oy);
+    const int gi = A.sym ? (v >> 3) : v;
+    return A.list ? A.list[gi] : gi;
+}
+
+// row of the output arrays for (virtual) board v
+__device__ inline int tower_dst(const TowerArgs &A, int v)
+{
+    if (A.sym)
+        return v;
+    return A.list ? A.list[v] : v;
+}
 
 template <int V> struct IC { static constexpr int value = V; };
 
@@ -397,7 +426,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     typedef typename Tr::afrag afrag;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = A.count ? *A.count : A.n;
+    const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
     const int tile0 = blockIdx.x * G::BOARDS;
     if (tile0 >= n)
         return;
@@ -420,8 +449,8 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     for (int cell = tid; cell < nb * 49; cell += NTHREADS) {
         const int bl = cell / 49, c = cell % 49;
         const int x = c / 7, y = c % 7;
-        const int sq = x + 7 * (6 - y);
-        const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
+        int sq;
+        const int game = tower_src(A, tile0 + bl, x, y, sq);
         const unsigned long long mover = A.boards[2 * (size_t)game + 0];
         const unsigned long long opp = A.boards[2 * (size_t)game + 1];
         const float f1 = (float)((mover >> sq) & 1ULL), f2 = (float)((opp >> sq) & 1ULL);
@@ -520,8 +549,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
             }
             if (cell < nb * 49) {
                 const int bl = cell / 49, c = cell % 49;
-                const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
-                float *dst = A.logits + (size_t)game * 833 + 17 * c;
+                float *dst = A.logits + (size_t)tower_dst(A, tile0 + bl) * 833 + 17 * c;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const int oc = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -535,7 +563,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     }
     __syncthreads();
     if (tid < nb) {
-        const int game = A.list ? A.list[tile0 + tid] : (tile0 + tid);
+        const int game = tower_dst(A, tile0 + tid);
         float s = 0.0f;
         for (int c = 0; c < 49; c++)
             s = __builtin_fmaf(vcell[tid * 49 + c], A.fc_w[c], s);
@@ -740,7 +768,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     typedef typename Tr::afrag afrag;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = A.count ? *A.count : A.n;
+    const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
     const int tile0 = blockIdx.x * G::BOARDS;
     if (tile0 >= n)
         return;
@@ -756,8 +784,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     for (int cell = tid; cell < nb * 49; cell += NTHREADS) {
         const int bl = cell / 49, c = cell % 49;
         const int x = c / 7, y = c % 7;
-        const int sq = x + 7 * (6 - y);
-        const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
+        int sq;
+        const int game = tower_src(A, tile0 + bl, x, y, sq);
         const unsigned long long mover = A.boards[2 * (size_t)game + 0];
         const unsigned long long opp = A.boards[2 * (size_t)game + 1];
         typename Tr::quad o;
@@ -842,8 +870,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
             }
             if (cell < nb * 49) {
                 const int bl = cell / 49, c = cell % 49;
-                const int game = A.list ? A.list[tile0 + bl] : (tile0 + bl);
-                float *dst = A.logits + (size_t)game * 833 + 17 * c;
+                float *dst = A.logits + (size_t)tower_dst(A, tile0 + bl) * 833 + 17 * c;
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     dst[4 * kg + i] = acc2[0][i];
@@ -856,7 +883,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     }
     __syncthreads();
     if (tid < nb) {
-        const int game = A.list ? A.list[tile0 + tid] : (tile0 + tid);
+        const int game = tower_dst(A, tile0 + tid);
         float s = 0.0f;
         for (int c = 0; c < 49; c++)
             s = __builtin_fmaf(*reinterpret_cast<const float *>(smem + G::vcell_off(tid * 49 + c)), A.fc_w[c], s);
@@ -1114,11 +1141,72 @@ static int tower_boards()
     return v;
 }
 
+// evaluate (nn_evals.py:48-62): logits of symmetry s are brought back with the spatial inverse
+// symmetry (the 17 move-type layers are NOT permuted: the reference averages them as they are) and
+// averaged in the fixed order s = 0..7; the value is the mean of the eight tanh outputs.
+__global__ __launch_bounds__(256) void k_sym_reduce(const float *__restrict__ sym_logits, const float *__restrict__ sym_values,
+                                                    const int *__restrict__ list, const int *__restrict__ count, int n_max,
+                                                    float *__restrict__ logits, float *__restrict__ values)
+{
+    const int n = count ? *count : n_max;
+    const int i = blockIdx.x;
+    if (i >= n)
+        return;
+    const int game = list ? list[i] : i;
+    const int inv[8] = {0, 1, 2, 3, 4, 6, 5, 7};  // nn_evals.py:27
+    for (int idx = threadIdx.x; idx < 833; idx += blockDim.x) {
+        const int c = idx / 17, l = idx % 17;
+        const int x = c / 7, y = c % 7;
+        float acc = 0.0f;
+        for (int s = 0; s < 8; s++) {
+            int ox, oy;
+            sym_cell(inv[s], x, y, ox, oy);
+            acc += sym_logits[((size_t)i * 8 + s) * 833 + 17 * (7 * ox + oy) + l];
+        }
+        logits[(size_t)game * 833 + idx] = acc * 0.125f;
+    }
+    if (threadIdx.x == 0) {
+        float acc = 0.0f;
+        for (int s = 0; s < 8; s++)
+            acc += sym_values[(size_t)i * 8 + s];
+        values[game] = acc * 0.125f;
+    }
+}
+
 // Evaluate up to max_n boards (dense list `list`/`count` on the device, or the
 // first n boards when both are null).  Everything is indexed by game.
+static int net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
+                      const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
+                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym);
+
 int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                    const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
                    float *d_values, hipStream_t stream, unsigned long long *d_stamps)
+{
+    return net_launch(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_logits, d_values, stream, d_stamps, 0);
+}
+
+// Symmetry-averaged evaluation: the tower runs 8 * n virtual boards into the scratch arrays
+// (d_tmp_logits [8 max_n][833], d_tmp_values [8 max_n]), k_sym_reduce writes the averages by game.
+int azh_net_launch_sym(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
+                       const int *d_count, int max_n, unsigned long long blockers, float *d_tmp_logits,
+                       float *d_tmp_values, float *d_logits, float *d_values, hipStream_t stream)
+{
+    if (max_n <= 0)
+        return 0;
+    int rc = net_launch(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_tmp_logits, d_tmp_values, stream,
+                        nullptr, 1);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_sym_reduce, dim3(max_n), dim3(256), 0, stream, (const float *)d_tmp_logits,
+                       (const float *)d_tmp_values, d_list, d_count, max_n, d_logits, d_values);
+    AZH_HIP(hipGetLastError());
+    return 0;
+}
+
+static int net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
+                      const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
+                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym)
 {
     if (dtype < 0 || dtype > 2)
         return azh_fail(-2, "bad dtype %d", dtype);
@@ -1141,6 +1229,9 @@ int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, 
     a.logits = d_logits;
     a.values = d_values;
     a.stamps = d_stamps;
+    a.sym = sym;
+    if (sym)
+        max_n *= 8;  // grid size: virtual boards
     const bool six = tower_boards() == 6;
     if (tower_variant() == 2 && dtype != AZH_DTYPE_F32) {
         if (d_stamps)
@@ -1186,6 +1277,35 @@ extern "C" int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *l
     (void)hipFree(d_b);
     (void)hipFree(d_l);
     (void)hipFree(d_v);
+    return rc;
+}
+
+extern "C" int azh_net_forward_sym(azh_net *net, int dtype, int n, const uint64_t *leaf_boards,
+                                   uint64_t blockers, float *logits_out, float *values_out)
+{
+    if (!net || !leaf_boards || !logits_out || !values_out || n < 0)
+        return azh_fail(-1, "azh_net_forward_sym: bad argument");
+    if (n == 0)
+        return 0;
+    unsigned long long *d_b = nullptr;
+    float *d_l = nullptr, *d_v = nullptr, *d_tl = nullptr, *d_tv = nullptr;
+    AZH_HIP(hipMalloc((void **)&d_b, (size_t)n * 16));
+    AZH_HIP(hipMalloc((void **)&d_l, (size_t)n * 833 * 4));
+    AZH_HIP(hipMalloc((void **)&d_v, (size_t)n * 4));
+    AZH_HIP(hipMalloc((void **)&d_tl, (size_t)n * 8 * 833 * 4));
+    AZH_HIP(hipMalloc((void **)&d_tv, (size_t)n * 8 * 4));
+    AZH_HIP(hipMemcpy(d_b, leaf_boards, (size_t)n * 16, hipMemcpyHostToDevice));
+    int rc = azh_net_launch_sym(net, dtype, d_b, nullptr, nullptr, n, blockers, d_tl, d_tv, d_l, d_v, 0);
+    if (rc == 0) {
+        AZH_HIP(hipDeviceSynchronize());
+        AZH_HIP(hipMemcpy(logits_out, d_l, (size_t)n * 833 * 4, hipMemcpyDeviceToHost));
+        AZH_HIP(hipMemcpy(values_out, d_v, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_b);
+    (void)hipFree(d_l);
+    (void)hipFree(d_v);
+    (void)hipFree(d_tl);
+    (void)hipFree(d_tv);
     return rc;
 }
 

@@ -25,6 +25,7 @@ DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTY
 LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
 FLAG_NO_REUSE, FLAG_TIE_FIRST, FLAG_PY_POSTERIOR, FLAG_SAMPLE_POW5, FLAG_KEEP_UNFINISHED, FLAG_TWO_NETS = 1, 2, 4, 8, 16, 32
 FLAG_ARENA = 63
+FLAG_SYMMETRY_AVG = 128    # nn_evals.py:48-62 on every evaluation
 FLAG_ONE_RANDOM_MOVE = 64  # cpp/self_play_client.cpp:515-552 (compile-time variant of the reference client)
 STAT_NAMES = ["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
               "edge_overflow", "reroot_nodes", "reroot_edges", "ring_overflow"]
@@ -74,6 +75,7 @@ SIGNATURES = {
     "azh_net_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _f32, _P(_vp)]),
     "azh_net_destroy": (None, [_vp]),
     "azh_net_forward": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
+    "azh_net_forward_sym": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
     "azh_net_bench": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P(_f32)]),
     "azh_net_stamps": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "azh_engine_create": (ctypes.c_int, [_P(Config), _P(_vp)]),
@@ -244,6 +246,15 @@ class Net:
         logits = np.zeros((n, 7, 7, 17), dtype=np.float32)
         values = np.zeros((n, 1), dtype=np.float32)
         check(load().azh_net_forward(self.h, dtype, n, _ptr(leaf_boards), int(blockers), _ptr(logits), _ptr(values)))
+        return logits, values
+
+    def forward_sym(self, leaf_boards, blockers, dtype=DTYPE_BF16):
+        """nn_evals.evaluate (nn_evals.py:48-62): mean over the 8 dihedral images, one tower launch."""
+        leaf_boards = np.ascontiguousarray(leaf_boards, dtype=np.uint64).reshape(-1, 2)
+        n = len(leaf_boards)
+        logits = np.zeros((n, 7, 7, 17), dtype=np.float32)
+        values = np.zeros((n, 1), dtype=np.float32)
+        check(load().azh_net_forward_sym(self.h, dtype, n, _ptr(leaf_boards), int(blockers), _ptr(logits), _ptr(values)))
         return logits, values
 
     def bench(self, n, iters=20, dtype=DTYPE_BF16):

@@ -96,7 +96,10 @@ class Position:
 class Searcher:
     TIME_CAP_VISITS = 20000  # arena size of a time-controlled search
 
-    def __init__(self, network_path, dtype="bf16"):
+    def __init__(self, network_path, dtype="bf16", symmetry_average=False):
+        # symmetry_average: every evaluation is nn_evals.evaluate (nn_evals.py:48-62); with one game the
+        # eight images ride in the same tower launch, so it costs no time
+        self.extra_flags = link.FLAG_SYMMETRY_AVG if symmetry_average else 0
         conv, bn = model.load_model(network_path)
         self.net = link.Net(conv, bn, model.BN_EPSILON)
         self.dtype = link.DTYPES[dtype]
@@ -108,7 +111,8 @@ class Searcher:
         cap = visits if visits is not None else self.TIME_CAP_VISITS
         cfg = link.Config(games=1, visits=cap + 1, max_plies=400, edges_per_node=96, c_puct=1.0, dirichlet_alpha=0.15,
                           dirichlet_weight=0.0, start_turn=pos.turn, seed=random.getrandbits(63), start_x=pos.x,
-                          start_o=pos.o, blockers=0, flags=link.FLAG_TIE_FIRST | link.FLAG_PY_POSTERIOR)
+                          start_o=pos.o, blockers=0,
+                          flags=link.FLAG_TIE_FIRST | link.FLAG_PY_POSTERIOR | self.extra_flags)
         eng = link.Engine(cfg)
         start = time.time()
         try:

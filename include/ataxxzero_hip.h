@@ -99,6 +99,11 @@ void azh_net_destroy(azh_net *net);
  * (tanh value, model.py:71-79), for n leaf boards (mover, opponent). */
 int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards, uint64_t blockers,
                     float *logits_out, float *values_out);
+/* The same with test-time symmetry averaging, nn_evals.evaluate (nn_evals.py:48-62): the tower runs the 8
+ * dihedral images of every board in one launch; logits come back through the inverse symmetry
+ * (spatially) and are averaged, values are averaged. */
+int azh_net_forward_sym(azh_net *net, int dtype, int n, const uint64_t *leaf_boards, uint64_t blockers,
+                        float *logits_out, float *values_out);
 
 /* Measurement hook: average HIP-event milliseconds per launch of the tower kernel over
  * n synthetic boards (iters launches on one stream, 3 untimed warm-up launches). */
@@ -142,6 +147,9 @@ enum {
     AZH_FLAG_TWO_NETS = 32,       /* arena: the side to move alternates between two nets; slot parity picks
                                      which net plays x; records carry "slot" and "uid" */
     AZH_FLAG_ARENA = 1 | 2 | 4 | 8 | 16 | 32,
+    AZH_FLAG_SYMMETRY_AVG = 128,  /* every evaluation is nn_evals.evaluate (nn_evals.py:48-62): the mean over the 8
+                                     dihedral symmetries of the board, logits brought back spatially (move-type
+                                     layers not permuted, as the reference), values averaged; 8x the tower work */
     AZH_FLAG_ONE_RANDOM_MOVE = 64 /* the ONE_RANDOM_MOVE build of the client (cpp/self_play_client.cpp:515-552):
                                      per game one ply in 0..119 plays a uniformly random legal move, every later
                                      ply the most visited move; the entry gains "random_ply" (train.py:47-49) */

@@ -68,3 +68,30 @@ def forward(conv_weights, bn_params, features, dtype=np.float64):
     v = conv2d_same(h, cw[2 * blocks + 2]).reshape(len(h), 49)                   # model.py:71-75
     value = np.tanh(v @ cw[2 * blocks + 3] + cw[2 * blocks + 4])                 # model.py:76-79
     return policy, value
+
+
+def apply_symmetry(tensor, symmetry):
+    """nn_evals.py:8-16 on a (7,7,k) tensor."""
+    if symmetry & 1:
+        tensor = tensor[::-1, :]
+    if symmetry & 2:
+        tensor = tensor[:, ::-1]
+    if symmetry & 4:
+        tensor = np.moveaxis(tensor, 0, 1)
+    return tensor
+
+
+INVERSE_SYMMETRY = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 6, 6: 5, 7: 7}   # nn_evals.py:27
+
+
+def forward_sym(conv_weights, bn_params, features, dtype=np.float64):
+    """nn_evals.evaluate (nn_evals.py:48-62) for a batch: the net on the 8 dihedral images of every
+    board, policies brought back with the inverse symmetry (spatial axes only) and averaged, values
+    averaged.  -> (policy (n,7,7,17), value (n,1))."""
+    features = np.asarray(features, dtype=dtype)
+    n = len(features)
+    images = np.stack([apply_symmetry(f, s) for f in features for s in range(8)])
+    policy, value = forward(conv_weights, bn_params, images, dtype=dtype)
+    policy = policy.reshape(n, 8, 7, 7, 17)
+    back = np.stack([np.stack([apply_symmetry(policy[i, s], INVERSE_SYMMETRY[s]) for s in range(8)]) for i in range(n)])
+    return back.mean(axis=1), value.reshape(n, 8).mean(axis=1).reshape(n, 1)

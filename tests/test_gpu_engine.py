@@ -158,3 +158,33 @@ def test_one_random_move_variant_matches_oracle():
         entry = json.loads(line)
         assert list(entry.keys()) == ["boards", "dists", "moves", "random_ply", "result"]
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+
+
+def test_symmetry_averaging_flag_in_the_device_loop_equals_host_evaluated_search():
+    # AZH_FLAG_SYMMETRY_AVG: every evaluation of the device loop is nn_evals.evaluate; the same search
+    # driven from the host with Net.forward_sym must build bit-identical trees (f32 tower on both sides)
+    conv, bn = model.random_init(1, 128, seed=31)
+    net = link.Net(conv, bn)
+    base = orc.make_config(9, 12, seed=4, max_plies=80, flags=link.FLAG_SYMMETRY_AVG)
+    mk = lambda: link.Engine(link.Config(**{n: getattr(base, n) for n, _ in orc.Config._fields_}))
+    dev, host = mk(), mk()
+    iters = 90
+    dev.run(net, iters, link.DTYPE_F32)
+    dev.sync()
+    for _ in range(iters):
+        host.select()
+        need, lb = host.leaves()
+        logits = np.zeros((9, 833), np.float32)
+        values = np.zeros(9, np.float32)
+        idx = np.nonzero(need)[0]
+        if len(idx):
+            p, v = net.forward_sym(lb[idx], base.blockers, link.DTYPE_F32)
+            logits[idx] = p.reshape(len(idx), 833)
+            values[idx] = v.reshape(-1)
+        host.set_evals(logits, values)
+        host.backup()
+    for g in range(9):
+        assert dev.game_state(g).as_tuple()[:6] == host.game_state(g).as_tuple()[:6]
+        for a, b in zip(dev.tree(g), host.tree(g)):
+            assert a.shape == b.shape and (a == b).all()
+    assert dev.stats()["plies"] == host.stats()["plies"] > 9

@@ -65,3 +65,23 @@ def test_reduced_precision_tower_tracks_f32(dtype, tol):
     # same argmax move on nearly every board
     same = (p.reshape(len(p), -1).argmax(1) == p32.reshape(len(p), -1).argmax(1)).mean()
     assert same >= 0.8
+
+
+def test_symmetry_averaged_forward_matches_nn_evals_restatement():
+    """azh_net_forward_sym == nn_evals.evaluate (nn_evals.py:48-62) as restated in float64; an asymmetric
+    blocker mask checks that the blocker plane is transformed with the board."""
+    conv, bn = model.random_init(2, 128, seed=21, perturb_bn=True)
+    net = link.Net(conv, bn)
+    for blockers in (BLOCK4_MASK, (1 << 0) | (1 << 9) | (1 << 33)):
+        lb = sample_leaf_boards(11, 6, blockers)
+        p, v = net.forward_sym(lb, blockers, link.DTYPE_F32)
+        feats = net_oracle.features_from_leaf_boards(lb, blockers)
+        ref_p, ref_v = net_oracle.forward_sym(conv, bn, feats)
+        assert np.abs(p - ref_p).max() <= 1e-5, np.abs(p - ref_p).max()
+        assert np.abs(v - ref_v).max() <= 1e-5
+        plain_p, _ = net_oracle.forward(conv, bn, feats)
+        assert np.abs(plain_p - ref_p).max() > 1e-3  # averaging changes the answer: the test is not vacuous
+        p16, v16 = net.forward_sym(lb, blockers, link.DTYPE_BF16)
+        assert np.abs(p16 - p).max() < 5e-2 and np.abs(v16 - v).max() < 5e-2
+    p0, v0 = net.forward_sym(lb[:0], 0, link.DTYPE_F32)
+    assert p0.shape == (0, 7, 7, 17)

@@ -44,7 +44,7 @@ def uai_decode_move(s):
 def main(args):
     from ataxxzero_amd import selfplay, uai
     selfplay.select_device(0)
-    searcher = uai.Searcher(args.network_path, dtype=args.dtype)
+    searcher = uai.Searcher(args.network_path, dtype=args.dtype, symmetry_average=args.symmetry_average)
     board = uai.Position.initial()
     while True:
         try:
@@ -90,6 +90,7 @@ if __name__ == "__main__":
     parser.add_argument("--visits", metavar="VISITS", default=None, type=int, help="Number of visits during MCTS.")
     parser.add_argument("--safety-ms", metavar="MS", default=0, type=int, help="Number of milliseconds to shave off of each movetime for safety.")
     parser.add_argument("--show-game", action="store_true", help="Show the game on stderr.")
+    parser.add_argument("--symmetry-average", action="store_true", help="Evaluate every position as the mean over its 8 dihedral images (nn_evals.py:48-62; extension).")
     parser.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="Tower arithmetic (extension).")
     args = parser.parse_args()
     print(args, file=sys.stderr)
