@@ -608,7 +608,26 @@ struct Geo2 {
     __device__ static int vcell_off(int c) { return (c / 40) * CS + 310 * UB + (c % 40) * 4; }
 };
 
-template <int DT, int KS, bool STAMP>
+// Cells of a workgroup are numbered c = 21 y + 7 board + x (the rows of the three boards interleaved): a
+// neighbour is still one uniform offset away (dx + 21 dy), and the 16-cell tiles 0 (cells 0..15: y = 0) and
+// 8, 9 (cells 128..146: y = 6) hold cells of one board edge only, so the taps that look past that edge are
+// all-zero for the whole tile and are skipped at compile time (B loads and MFMAs): 9 of the 90 (tile, tap)
+// pairs per layer.  The FLOP count reported for the kernel stays the padded-tap figure.
+__device__ inline void cell_xy(int c, int &bl, int &x, int &y)
+{
+    y = c / 21;
+    const int r = c - 21 * y;
+    bl = r / 7;
+    x = r - 7 * bl;
+}
+
+// CHF = cell half of the wave (tiles 5 CHF .. 5 CHF + 4); dyi = tap % 3 (dy + 1)
+template <int CHF> __device__ constexpr bool skip_pair(int ct, int dyi)
+{
+    return CHF == 0 ? (ct == 0 && dyi == 0) : ((ct == 3 || ct == 4) && dyi == 2);
+}
+
+template <int DT, int KS, int CHF, bool STAMP>
 __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, bool skip,
                                    const typename Traits<DT>::afrag *__restrict__ wp,
                                    typename Traits<DT>::afrag (&a)[2][4], f32x16 &sh, const float *__restrict__ shift_next,
@@ -620,7 +639,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     constexpr int TPW = G::TPW;
     constexpr int TOTAL = 9 * KS;
     const int r = lane & 15, kg = lane >> 4;
-    const int oh = wave >> 1, chf = wave & 1;
+    const int oh = wave >> 1;
     // accumulators [A tile][cell tile], started at the batch-norm shift (+ residual input)
     f32x4 acc[4][TPW];
 #pragma unroll
@@ -637,7 +656,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         typename Tr::quad sk[4][TPW];
 #pragma unroll
         for (int ct = 0; ct < TPW; ct++) {
-            const int cell = 16 * (TPW * chf + ct) + r;
+            const int cell = 16 * (TPW * CHF + ct) + r;
             const int slot = cell < G::NC ? G::real_slot(out_img, cell) : G::zero_slot(out_img, cell);
 #pragma unroll
             for (int t = 0; t < 4; t++)
@@ -670,58 +689,79 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         for (int t = 0; t < 4; t++)
             dst[t] = *reinterpret_cast<const afrag *>(p + t * 1024 + lane_off);
     };
-    auto rows_for = [&](int tap, int (&dst)[TPW]) {
-        const int drow = (tap / 3 - 1) * 7 + (tap % 3 - 1);
-#pragma unroll
-        for (int ct = 0; ct < TPW; ct++) {
-            const int c = 16 * (TPW * chf + ct) + r + drow;
-            const int slot = ((vmask[ct] >> tap) & 1) ? G::real_slot(in_img, c) : G::zero_slot(in_img, c);
-            dst[ct] = kg * G::CS + slot * G::UB;
-        }
+    // byte offsets of this lane's B fragments for tap (dxi, dyi); skipped pairs are left alone
+    auto rows_for = [&](int dxi, auto dyi_tag, int (&dst)[TPW]) {
+        constexpr int dyi = decltype(dyi_tag)::value;
+        const int tap = 3 * dxi + dyi;
+        const int drow = (dxi - 1) + 21 * (dyi - 1);
+        static_for<0, TPW>([&](auto ct_tag) {
+            constexpr int ct = decltype(ct_tag)::value;
+            if constexpr (!skip_pair<CHF>(ct, dyi)) {
+                const int c = 16 * (TPW * CHF + ct) + r + drow;
+                const int slot = ((vmask[ct] >> tap) & 1) ? G::real_slot(in_img, c) : G::zero_slot(in_img, c);
+                dst[ct] = kg * G::CS + slot * G::UB;
+            }
+        });
     };
-    auto load_b = [&](afrag (&bf)[TPW], const int (&rows)[TPW], int ks) {
-#pragma unroll
-        for (int ct = 0; ct < TPW; ct++)
-            bf[ct] = *reinterpret_cast<const afrag *>(lds + rows[ct] + ks * (4 * G::CS));
+    auto load_b = [&](afrag (&bf)[TPW], const int (&rows)[TPW], int ks, auto dyi_tag) {
+        constexpr int dyi = decltype(dyi_tag)::value;
+        static_for<0, TPW>([&](auto ct_tag) {
+            constexpr int ct = decltype(ct_tag)::value;
+            if constexpr (!skip_pair<CHF>(ct, dyi))
+                bf[ct] = *reinterpret_cast<const afrag *>(lds + rows[ct] + ks * (4 * G::CS));
+        });
     };
     afrag b[2][TPW];
     int cur[TPW], nxt[TPW];
-    auto one_step = [&](auto par_tag, const int (&src)[TPW], int ks_target, int s) {
-        constexpr int par = decltype(par_tag)::value;
-        load_b(b[par ^ 1], src, ks_target);
-        __builtin_amdgcn_sched_barrier(0);
+    // one dx row of taps = 3 KS steps, straight-line: step j consumes tap dyi = j / KS, k-step j % KS
+    auto dx_row = [&](int dxi, auto par0_tag) {
+        constexpr int par0 = decltype(par0_tag)::value;  // buffer parity of the row's first step
+        static_for<0, 3 * KS>([&](auto j_tag) {
+            constexpr int j = decltype(j_tag)::value;
+            constexpr int dyi = j / KS, ks = j % KS;
+            constexpr int par = (par0 + j) & 1;
+            constexpr int j1 = j + 1;
+            constexpr int dyi1 = (j1 / KS) % 3, ks1 = j1 % KS;
+            const int s = (3 * dxi + dyi) * KS + ks;
+            if constexpr (ks == 0) {  // offsets of the tap after this one (it may belong to the next dx row)
+                const int dx1 = dyi == 2 ? (dxi < 2 ? dxi + 1 : 2) : dxi;
+                rows_for(dx1, IC<(dyi + 1) % 3>(), nxt);
+            }
+            // prefetch the B fragments of step s + 1
+            if constexpr (ks1 == 0)
+                load_b(b[par ^ 1], nxt, 0, IC<dyi1>());
+            else
+                load_b(b[par ^ 1], cur, ks1, IC<dyi1>());
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+            for (int t = 0; t < 4; t++)
+                static_for<0, TPW>([&](auto ct_tag) {
+                    constexpr int ct = decltype(ct_tag)::value;
+                    if constexpr (!skip_pair<CHF>(ct, dyi))
+                        acc[t][ct] = Mfma16<DT>::mfma(a[par][t], b[par][ct], acc[t][ct]);
+                });
+            load_a(a[par], s + 2);
+            if constexpr (ks1 == 0) {
 #pragma unroll
-            for (int ct = 0; ct < TPW; ct++)
-                acc[t][ct] = Mfma16<DT>::mfma(a[par][t], b[par][ct], acc[t][ct]);
-        load_a(a[par], s + 2);
+                for (int ct = 0; ct < TPW; ct++)
+                    cur[ct] = nxt[ct];
+            }
+        });
     };
-    rows_for(0, cur);
-    load_b(b[0], cur, 0);
+    rows_for(0, IC<0>(), cur);
+#pragma unroll
+    for (int ct = 0; ct < TPW; ct++)
+        nxt[ct] = cur[ct];
+    load_b(b[0], cur, 0, IC<0>());
     if constexpr (STAMP) st[0] = stamp_now();
-    if constexpr (TOTAL <= 18) {
-        static_for<0, TOTAL>([&](auto s_tag) {
-            constexpr int s = decltype(s_tag)::value, t1 = s + 1;
-            constexpr int tap_t = t1 / KS < 9 ? t1 / KS : 8;
-            rows_for(tap_t, cur);
-            one_step(IC<(s & 1)>(), cur, t1 % KS, s);
+    if constexpr ((3 * KS) % 2 != 0) {
+        static_for<0, 3>([&](auto d_tag) {
+            constexpr int d = decltype(d_tag)::value;
+            dx_row(d, IC<(3 * KS * d) & 1>());
         });
     } else {
-        static_assert(KS % 2 == 0, "pipeline shape");
-        for (int tap = 0; tap < 9; tap++) {
-            rows_for(tap < 8 ? tap + 1 : 8, nxt);
-            static_for<0, KS>([&](auto j_tag) {
-                constexpr int j = decltype(j_tag)::value;
-                if constexpr (j + 1 < KS)
-                    one_step(IC<(j & 1)>(), cur, j + 1, tap * KS + j);
-                else
-                    one_step(IC<(j & 1)>(), nxt, 0, tap * KS + j);
-            });
-#pragma unroll
-            for (int ct = 0; ct < TPW; ct++)
-                cur[ct] = nxt[ct];
-        }
+        for (int dxi = 0; dxi < 3; dxi++)
+            dx_row(dxi, IC<0>());
     }
     if constexpr (STAMP) st[1] = stamp_now();
     fetch_shift();
@@ -736,7 +776,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     // epilogue: relu, convert, write 4 channels (8 bytes) per (A tile, cell tile)
 #pragma unroll
     for (int ct = 0; ct < TPW; ct++) {
-        const int cell = 16 * (TPW * chf + ct) + r;
+        const int cell = 16 * (TPW * CHF + ct) + r;
         if (cell < G::NC) {
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -760,6 +800,67 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     if constexpr (STAMP) st[2] = stamp_now();
 }
 
+template <int DT, int CHF, bool STAMP>
+__device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int tile0, int nb, int wave, int lane,
+                                   unsigned long long *st)
+{
+    typedef Traits<DT> Tr;
+    typedef Geo2 G;
+    typedef typename Tr::afrag afrag;
+    int vmask[G::TPW];
+    {
+        const int r = lane & 15;
+#pragma unroll
+        for (int ct = 0; ct < G::TPW; ct++) {
+            const int cell = 16 * (G::TPW * CHF + ct) + r;
+            int m = 0;
+            if (cell < G::NC) {
+                int bl, x, y;
+                cell_xy(cell, bl, x, y);
+                for (int tap = 0; tap < 9; tap++) {
+                    const int xx = x + tap / 3 - 1, yy = y + tap % 3 - 1;
+                    if (xx >= 0 && xx < 7 && yy >= 0 && yy < 7)
+                        m |= 1 << tap;
+                }
+            }
+            vmask[ct] = m;
+        }
+    }
+    const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w2);
+    const size_t l0 = (size_t)9 * G::KS_IN * 8 * 64, lf = (size_t)9 * G::KS_FULL * 8 * 64;
+    const int oh = wave >> 1, kg = lane >> 4;
+    afrag aring[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            aring[i][t] = wp[((size_t)i * 8 + 4 * oh + t) * 64 + lane];
+    f32x16 sh;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(A.shift + 64 * oh + 16 * t + 4 * kg);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            sh[4 * t + i] = t4[i];
+    }
+    if constexpr (STAMP) st[1] = stamp_now();
+    conv_layer2<DT, G::KS_IN, CHF, STAMP>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
+    __syncthreads();
+    if constexpr (STAMP) st[7] = stamp_now();
+    wp += l0;
+    for (int b = 0; b < A.blocks; b++) {
+        const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
+        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, wave, lane, st + 8 + 8 * b);
+        __syncthreads();
+        if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
+        wp += lf;
+        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, wave, lane, st + 12 + 8 * b);
+        __syncthreads();
+        if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
+        wp += lf;
+    }
+}
+
 template <int DT, bool STAMP = false>
 __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
 {
@@ -781,77 +882,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     for (int i = tid * 16; i < G::LDS_BYTES; i += NTHREADS * 16)
         *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    for (int cell = tid; cell < nb * 49; cell += NTHREADS) {
-        const int bl = cell / 49, c = cell % 49;
-        const int x = c / 7, y = c % 7;
-        int sq;
-        const int game = tower_src(A, tile0 + bl, x, y, sq);
-        const unsigned long long mover = A.boards[2 * (size_t)game + 0];
-        const unsigned long long opp = A.boards[2 * (size_t)game + 1];
-        typename Tr::quad o;
-        o[0] = (typename Tr::elem)1.0f;
-        o[1] = (typename Tr::elem)(float)((mover >> sq) & 1ULL);
-        o[2] = (typename Tr::elem)(float)((opp >> sq) & 1ULL);
-        o[3] = (typename Tr::elem)(float)((A.blockers >> sq) & 1ULL);
-        *reinterpret_cast<typename Tr::quad *>(smem + G::ch_off(G::real_slot(0, cell), 0)) = o;
-    }
-    int vmask[G::TPW];
-    {
-        const int r = lane & 15, chf = wave & 1;
-#pragma unroll
-        for (int ct = 0; ct < G::TPW; ct++) {
-            const int cell = 16 * (G::TPW * chf + ct) + r;
-            int m = 0;
-            if (cell < G::NC) {
-                const int c = cell % 49, x = c / 7, y = c % 7;
-                for (int tap = 0; tap < 9; tap++) {
-                    const int xx = x + tap / 3 - 1, yy = y + tap % 3 - 1;
-                    if (xx >= 0 && xx < 7 && yy >= 0 && yy < 7)
-                        m |= 1 << tap;
-                }
-            }
-            vmask[ct] = m;
+    // input planes (cpp/self_play_client.cpp:174-202): ones, mover, opponent, blockers
+    for (int cell = tid; cell < G::NC; cell += NTHREADS) {
+        int bl, x, y;
+        cell_xy(cell, bl, x, y);
+        if (bl < nb) {
+            int sq;
+            const int game = tower_src(A, tile0 + bl, x, y, sq);
+            const unsigned long long mover = A.boards[2 * (size_t)game + 0];
+            const unsigned long long opp = A.boards[2 * (size_t)game + 1];
+            typename Tr::quad o;
+            o[0] = (typename Tr::elem)1.0f;
+            o[1] = (typename Tr::elem)(float)((mover >> sq) & 1ULL);
+            o[2] = (typename Tr::elem)(float)((opp >> sq) & 1ULL);
+            o[3] = (typename Tr::elem)(float)((A.blockers >> sq) & 1ULL);
+            *reinterpret_cast<typename Tr::quad *>(smem + G::ch_off(G::real_slot(0, cell), 0)) = o;
         }
     }
     __syncthreads();
-
-    const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w2);
-    const size_t l0 = (size_t)9 * G::KS_IN * 8 * 64, lf = (size_t)9 * G::KS_FULL * 8 * 64;
-    const int oh = wave >> 1, kg = lane >> 4;
-    afrag aring[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            aring[i][t] = wp[((size_t)i * 8 + 4 * oh + t) * 64 + lane];
-    f32x16 sh;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(A.shift + 64 * oh + 16 * t + 4 * kg);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            sh[4 * t + i] = t4[i];
-    }
-    if constexpr (STAMP) st[1] = stamp_now();
-    conv_layer2<DT, G::KS_IN, STAMP>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
-    __syncthreads();
-    if constexpr (STAMP) st[7] = stamp_now();
-    wp += l0;
-    for (int b = 0; b < A.blocks; b++) {
-        const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer2<DT, G::KS_FULL, STAMP>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, wave, lane, st + 8 + 8 * b);
-        __syncthreads();
-        if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
-        wp += lf;
-        conv_layer2<DT, G::KS_FULL, STAMP>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, wave, lane, st + 12 + 8 * b);
-        __syncthreads();
-        if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
-        wp += lf;
-    }
+    // the two cell halves run separate instantiations: which (tile, tap) pairs are skipped is compile-time
+    if (wave & 1)
+        tower2_body<DT, 1, STAMP>(A, smem, tile0, nb, wave, lane, st);
+    else
+        tower2_body<DT, 0, STAMP>(A, smem, tile0, nb, wave, lane, st);
     // heads: two 16-row A tiles (policy 0-15 | policy 16, value conv, pad); cell tiles dealt to the waves
     {
         const afrag *hp = reinterpret_cast<const afrag *>(A.head_w2) + lane;
-        const int r = lane & 15;
+        const int r = lane & 15, kg = lane >> 4;
         for (int ct = wave; ct < G::NT; ct += OCT) {
             f32x4 acc2[2];
 #pragma unroll
@@ -868,9 +925,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
                 for (int t = 0; t < 2; t++)
                     acc2[t] = Mfma16<DT>::mfma(hp[(size_t)(ks * 2 + t) * 64], bfrag, acc2[t]);
             }
-            if (cell < nb * 49) {
-                const int bl = cell / 49, c = cell % 49;
-                float *dst = A.logits + (size_t)tower_dst(A, tile0 + bl) * 833 + 17 * c;
+            int bl = 0, x = 0, y = 0;
+            if (cell < G::NC)
+                cell_xy(cell, bl, x, y);
+            if (cell < G::NC && bl < nb) {
+                float *dst = A.logits + (size_t)tower_dst(A, tile0 + bl) * 833 + 17 * (7 * x + y);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     dst[4 * kg + i] = acc2[0][i];
@@ -885,8 +944,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     if (tid < nb) {
         const int game = tower_dst(A, tile0 + tid);
         float s = 0.0f;
-        for (int c = 0; c < 49; c++)
-            s = __builtin_fmaf(*reinterpret_cast<const float *>(smem + G::vcell_off(tid * 49 + c)), A.fc_w[c], s);
+        for (int c = 0; c < 49; c++)  // c = 7 x + y, model.py:75's reshape order
+            s = __builtin_fmaf(*reinterpret_cast<const float *>(smem + G::vcell_off(21 * (c % 7) + 7 * tid + c / 7)), A.fc_w[c], s);
         A.values[game] = tanhf(s + A.fc_b);
     }
     if constexpr (STAMP) st[2] = stamp_now();
