@@ -39,7 +39,7 @@ constexpr int REC_MAXD = 256;
 constexpr int REC_STRIDE_WORDS = REC_HDR_WORDS + REC_MAXD;
 constexpr u32 RING_MAGIC = 0x415A4847u;  // "AZHG"
 constexpr int NSTAT = AZH_STAT_COUNT;
-constexpr int BFS_QL = 512;  // re-root frontier entries kept in LDS; later ones spill to bfs_spill in HBM
+constexpr int BFS_QL = 384;  // re-root frontier entries kept in LDS; later ones spill to bfs_spill in HBM
 
 struct EngineParams {
     int G, visits, node_cap, edge_cap, path_cap, max_plies;
@@ -76,9 +76,14 @@ struct EngineParams {
 struct TreeLds {
     u16 moves[MAX_MOVES];
     u32 old[WAVE], pref[WAVE + 1];
-    u64 w[MAX_MOVES];
-    u32 q[4][BFS_QL];  // frontier queue: old node id, old first edge, n_edges | result << 16, parent edge
+    union {              // the sampling weights are dead before the re-root copy starts
+        u64 w[MAX_MOVES];
+        u32 q[4][BFS_QL];  // frontier queue: old node id, old first edge, n_edges | result << 16, parent edge
+    };
 };
+// All G waves of a launch must be resident at once (the kernel lasts as long as its deepest descent):
+// 16 games per CU at G = 4096, so the scratch has to stay under 160 KiB / 16.
+static_assert(sizeof(TreeLds) <= 8192, "TreeLds: keep >= 20 game waves per CU");
 
 struct Arena {
     ulonglong2 *nb;
@@ -226,7 +231,12 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
             // the floats and (bits << 32 | index or ~index) is a total order; NaN scores (never
             // selected by either reference) and empty lanes map to key 0.
             const u32 tie_flip = (P.flags & AZH_FLAG_TIE_FIRST) ? 0xFFFFFFFFu : 0u;
+            // every lane keeps the child data of its own best edge: the winning lane's best IS the winner, so
+            // no array is indexed by the (run-time) round of the winner (that put the arrays in scratch memory
+            // and a scratch round trip into every level)
             u64 key = 0;
+            u32 mine = ev[0].w;
+            u32 mkx = kv[0].x, mky = kv[0].y;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int j = lane + 64 * k;
@@ -238,23 +248,25 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
                     const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
                     const float score = u + q;
                     const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)((u32)j ^ tie_flip) : 0ull;
-                    key = kj > key ? kj : key;
+                    if (kj > key) {
+                        key = kj;
+                        mine = ev[k].w;
+                        mkx = kv[k].x;
+                        mky = kv[k].y;
+                    }
                 }
             }
             key = wave_max_u64(key);
-            const int bj = key ? (int)((u32)key ^ tie_flip) : 0;
+            const int bj = key ? (int)((u32)key ^ tie_flip) : 0;  // key 0: edge 0 = lane 0's round-0 default
             const u32 eidx = first + (u32)bj;
             if (lane == 0)
                 path[depth] = (int)eidx;
             depth++;
-            const int kk = bj >> 6;
-            const u32 mine = kk == 0 ? ev[0].w : (kk == 1 ? ev[1].w : (kk == 2 ? ev[2].w : ev[3].w));
-            const uint2 mkid = kk == 0 ? kv[0] : (kk == 1 ? kv[1] : (kk == 2 ? kv[2] : kv[3]));
             const u32 child = (u32)read_lane((int)mine, bj & 63);
             if (child != NONE) {
                 node = child;
-                first = (u32)read_lane((int)mkid.x, bj & 63);
-                ninfo = (u32)read_lane((int)mkid.y, bj & 63);
+                first = (u32)read_lane((int)mkx, bj & 63);
+                ninfo = (u32)read_lane((int)mky, bj & 63);
                 continue;
             }
             // expand (:429-439)
@@ -318,12 +330,16 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
         P.leaf_board[g] = make_ulonglong2(leaf_mover, leaf_opp);
         if (over)
             P.force[g] = 1;
-        add_stat(P, g, AZH_STAT_STEPS, st_steps);
-        add_stat(P, g, AZH_STAT_NN_EVALS, st_evals);
-        add_stat(P, g, AZH_STAT_LEVELS, st_levels);
-        add_stat(P, g, AZH_STAT_CHILDREN, st_children);
-        add_stat(P, g, AZH_STAT_NEW_MOVES, st_newmoves);
-        add_stat(P, g, AZH_STAT_EDGE_OVERFLOW, (u64)(over == 1));
+    }
+    {   // counters: lane k owns counter k, one read-modify-write round trip for all of them
+        const u64 inc = lane == AZH_STAT_STEPS ? st_steps
+                      : lane == AZH_STAT_NN_EVALS ? st_evals
+                      : lane == AZH_STAT_LEVELS ? st_levels
+                      : lane == AZH_STAT_CHILDREN ? st_children
+                      : lane == AZH_STAT_NEW_MOVES ? st_newmoves
+                      : lane == AZH_STAT_EDGE_OVERFLOW ? (u64)(over == 1) : 0ull;
+        if (lane < NSTAT)
+            add_stat(P, g, lane, inc);
     }
 }
 
@@ -803,12 +819,16 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     if (lane == 0) {
         P.force[g] = 0;
         P.gs[g] = s;
-        add_stat(P, g, AZH_STAT_PLIES, 1);
-        add_stat(P, g, AZH_STAT_GAMES, st_games);
-        add_stat(P, g, AZH_STAT_DROPPED, st_dropped);
-        add_stat(P, g, AZH_STAT_RING_OVERFLOW, st_ring);
-        add_stat(P, g, AZH_STAT_REROOT_NODES, st_nodes);
-        add_stat(P, g, AZH_STAT_REROOT_EDGES, st_edges);
+    }
+    {
+        const u64 inc = lane == AZH_STAT_PLIES ? 1ull
+                      : lane == AZH_STAT_GAMES ? (u64)st_games
+                      : lane == AZH_STAT_DROPPED ? (u64)st_dropped
+                      : lane == AZH_STAT_RING_OVERFLOW ? (u64)st_ring
+                      : lane == AZH_STAT_REROOT_NODES ? st_nodes
+                      : lane == AZH_STAT_REROOT_EDGES ? st_edges : 0ull;
+        if (lane < NSTAT)
+            add_stat(P, g, lane, inc);
     }
 }
 
