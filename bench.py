@@ -75,9 +75,58 @@ def cpu_baseline(conv, bn, visits, seconds=15.0, games=128):
         iters += 1
     dt = time.time() - t0
     st = eng.stats()
+    # the tree side alone (null evaluator: zero logits, zero value), as SURVEY 8(d) asks beside the full figure
+    eng2 = orc.Engine(orc.make_config(games=games, visits=visits, seed=20260101))
+    zl, zv = np.zeros((games, 833), np.float32), np.zeros(games, np.float32)
+    t2 = time.time()
+    while time.time() - t2 < min(3.0, seconds):
+        eng2.select()
+        eng2.backup(zl, zv)
+    tree_only = eng2.stats()["steps"] / (time.time() - t2)
     return {"value": st["steps"] / dt, "unit": "node-evals/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "tree_only_value": tree_only,
             "sample": "%d concurrent games x %d iterations (%.1f s): oracle tree search (1 thread) + numpy f32 "
-                      "conv tower (BLAS threads = host cores), same net / sims-per-move" % (games, iters, dt)}
+                      "conv tower (BLAS threads = host cores), same net / sims-per-move; tree_only_value = the same "
+                      "search with a null evaluator, 1 thread" % (games, iters, dt)}
+
+
+def target_leg(conv, bn, args, games=16384, steps=300, warmup=100):
+    """BASELINE.json's north-star operating point (>= 10k concurrent games on one GPU, 400 sims/move) measured
+    the same way as the headline, reported beside it (never as `value`)."""
+    from ataxxzero_amd import model, selfplay
+    sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=args.dtype, seed=selfplay.DEFAULT_SEED + 77)
+    def run(iters):
+        done = 0
+        while done < iters:
+            n = min(args.chunk, iters - done)
+            sp.run(n)
+            sp.drain()
+            done += n
+
+    try:
+        sp.set_visits(min(16, args.visits))
+        run(args.phase_mix)
+        sp.set_visits(args.visits)
+        run(300)
+        run(warmup)
+        sp.sync()
+        st0 = sp.stats()
+        sp.timing_reset(True)
+        t0 = time.perf_counter()
+        run(steps)
+        sp.sync()
+        dt = time.perf_counter() - t0
+        st1 = sp.stats()
+        tm = sp.timing()
+        it = max(tm["iterations"], 1)
+        evals = (st1["nn_evals"] - st0["nn_evals"]) * it / float(steps)
+        tf = evals * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] * 1e-3) / 1e12
+        return {"games": games, "node_evals_per_s": (st1["steps"] - st0["steps"]) / dt, "ms_per_step": 1e3 * dt / steps,
+                "steps": steps,
+                "tower_ms_per_launch": tm["net_ms"] / it, "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[args.dtype],
+                "tree_ms_per_step": (tm["select_ms"] + tm["backup_ms"]) / it}
+    finally:
+        sp.close()
 
 
 def main():
@@ -97,6 +146,7 @@ def main():
                          "iterations at full sims/move that regrow the trees; then the --warmup steps")
     ap.add_argument("--phase-fill", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-target-leg", action="store_true", help="skip the 16384-game leg reported beside the headline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -185,11 +235,15 @@ def main():
                               "children_per_step": d["children"] / float(max(d["steps"], 1))},
             "counters": d,
         }
+        sp.close()
+        if group.world == 1 and not args.no_target_leg and args.streams == 1:
+            out["target_10k_games"] = target_leg(conv, bn, args)
         if group.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(conv, bn, args.visits, seconds=args.cpu_seconds)
         print(json.dumps(out))
         sys.stdout.flush()
-    sp.close()
+    else:
+        sp.close()
     group.close()
 
 
