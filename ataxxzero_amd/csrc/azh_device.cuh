@@ -196,6 +196,18 @@ __device__ inline float wave_max_f32(float v)
     return __int_as_float(bcast_last(__float_as_int(v)));
 }
 
+__device__ inline u32 wave_max_u32(u32 v)
+{
+    const auto mx = [](u32 a, u32 b) { return b > a ? b : a; };
+    v = mx(v, (u32)dpp_i32<0xB1>((int)v, (int)v));
+    v = mx(v, (u32)dpp_i32<0x4E>((int)v, (int)v));
+    v = mx(v, (u32)dpp_i32<0x141>((int)v, (int)v));
+    v = mx(v, (u32)dpp_i32<0x140>((int)v, (int)v));
+    v = mx(v, (u32)dpp_i32<0x142, 0xA>((int)v, (int)v));
+    v = mx(v, (u32)dpp_i32<0x143, 0xC>((int)v, (int)v));
+    return (u32)bcast_last((int)v);
+}
+
 // max of a 64-bit key (used for arg-max as (score bits << 32) | index)
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ inline u64 dpp_max_u64(u64 v)

@@ -209,6 +209,47 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
             }
             st_levels += 1;
             st_children += (u64)M;
+            u32 sel_eidx = 0;
+            if (M <= WAVE) {
+                // Fast path (nearly every node): one edge per lane.  Same arithmetic as the general path below;
+                // the arg-max is a 32-bit max of the score bits plus a ballot for the tie rule, instead of a
+                // 64-bit (score, index) key reduction — this loop is a latency chain, instructions count.
+                uint4 e1 = make_uint4(0u, 0u, 0u, NONE);
+                uint2 k1 = make_uint2(0u, 0u);
+                const bool live = lane < M;
+                if (live) {
+                    e1 = A.ed[first + lane];
+                    k1 = A.ek[first + lane];
+                }
+                const u32 ntot1 = wave_sum_u32(e1.y);
+                const float sq1 = sqrtf((float)(1u + ntot1));
+                const float prior = u2f(e1.x);
+                const u32 n = e1.y;
+                const float W = u2f(e1.z);
+                const float q = n ? W / (float)n : 0.0f;
+                const float u = (sq1 / (1.0f + (float)n)) * (P.c_puct * prior);
+                const float score = u + q;
+                const bool valid = live && score >= 0.0f;  // NaN scores are never selected by either reference
+                const u32 bits = valid ? f2u(score + 0.0f) : 0u;
+                const u32 top = wave_max_u32(bits);
+                const u64 cand = __ballot(valid && bits == top);
+                int bj = 0;
+                if (cand)
+                    bj = (P.flags & AZH_FLAG_TIE_FIRST) ? (__ffsll((long long)cand) - 1) : (63 - __clzll((long long)cand));
+                const u32 eidx = first + (u32)bj;
+                if (lane == 0)
+                    path[depth] = (int)eidx;
+                depth++;
+                const u32 child = (u32)read_lane((int)e1.w, bj);
+                if (child != NONE) {
+                    node = child;
+                    first = (u32)read_lane((int)k1.x, bj);
+                    ninfo = (u32)read_lane((int)k1.y, bj);
+                    continue;
+                }
+                // fall through to the expansion below with the general path's variable
+                sel_eidx = eidx;
+            } else {
             const int rounds = (M + 63) >> 6;
             uint4 ev[4];
             uint2 kv[4];
@@ -269,7 +310,10 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
                 ninfo = (u32)read_lane((int)mky, bj & 63);
                 continue;
             }
+            sel_eidx = eidx;
+            }
             // expand (:429-439)
+            const u32 eidx = sel_eidx;
             const u32 mv = A.em[eidx];
             const ulonglong2 pw = A.nb[node];
             const Board cb = make_move(unpack_board(pw.x, pw.y), (int)(mv & 0xFF), (int)(mv >> 8));
@@ -967,6 +1011,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     P.blockers = cfg->blockers;
     P.start_turn = cfg->start_turn;
     P.flags = cfg->flags;
+
     const size_t G = (size_t)P.G;
     // ring of finished-game records (64 KiB per slot between two drains)
     P.ring_cap_words = std::max<size_t>((size_t)1 << 22, G * 16384);

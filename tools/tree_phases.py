@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ataxxzero_amd import link, model, selfplay
 conv, bn = model.random_init(12, 128, seed=1)
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+G = int(sys.argv[1]) if len(sys.argv) > 1 else int(os.environ.get("GAMES", "4096"))
 sp = selfplay.SelfPlay(conv, bn, games=G, visits=400, dtype="bf16")
 sp.set_visits(16); sp.run(2500); sp.set_visits(400); sp.run(700); sp.sync()
 e = sp.engine
