@@ -48,8 +48,11 @@ struct EngineParams {
     u64 start_x, start_o, blockers;
     int start_turn;
     u32 flags;
+    int select_budget;  // tree levels per select launch and game (0 = unlimited), azh_config.select_budget
     azh_game_state *gs;
     int *force;
+    int *adv_list;   // games whose move is due (phase 2), appended by mark_game, consumed by k_advance_list
+    int *adv_count;
     int *path;
     ulonglong2 *node_board;
     uint4 *node_info;
@@ -181,7 +184,10 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
     u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0;
     u64 leaf_mover = 0, leaf_opp = 0;
 
-    if (s.phase == 0 && (P.flags & AZH_FLAG_TWO_NETS) && (A.ni[0].y & 0xFFFFu) == 1u) {
+    if (s.phase == 2) {
+        // the move of this game is due: its re-root runs after this select (k_advance_list), no leaf now
+        kind = AZH_LEAF_NONE;
+    } else if (s.phase == 0 && (P.flags & AZH_FLAG_TWO_NETS) && (A.ni[0].y & 0xFFFFu) == 1u) {
         // arena: a single legal move is played without search (uai_ringmaster.py:114-116)
         kind = AZH_LEAF_NONE;
         s.phase = 1;
@@ -195,11 +201,22 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
         leaf_mover = b.turn ? b.o : b.x;
         leaf_opp = b.turn ? b.x : b.o;
     } else {
-        st_steps = 1;
-        u32 node = 0;
-        const uint4 rinfo = A.ni[0];
+        // a descent parked by the level budget resumes at the node it stopped at (same tree: nothing of this
+        // game was touched in between)
+        const bool resume = s.leaf_kind == AZH_LEAF_DESCENT;
+        st_steps = resume ? 0 : 1;
+        u32 node = resume ? (u32)s.leaf_node : 0u;
+        depth = resume ? s.path_len : 0;
+        const uint4 rinfo = A.ni[node];
         u32 first = rinfo.x, ninfo = rinfo.y;  // edge range + result of the node being scanned
+        int levels_done = 0;
         for (;;) {
+            if (P.select_budget != 0 && levels_done == P.select_budget) {
+                kind = AZH_LEAF_DESCENT;  // park: no leaf for the evaluator from this game this iteration
+                leaf_node = (int)node;
+                break;
+            }
+            levels_done++;
             const int M = (int)(ninfo & 0xFFFFu);
             const int result = (int)(ninfo >> 16);
             if (result != 0 || M == 0) {
@@ -420,8 +437,8 @@ __device__ inline void backup_game(const EngineParams &P, int g)
     const int lane = lane_id();
     azh_game_state s = P.gs[g];
     const int kind = s.leaf_kind;
-    if (kind == AZH_LEAF_NONE)
-        return;
+    if (kind == AZH_LEAF_NONE || kind == AZH_LEAF_DESCENT)
+        return;  // nothing evaluated; a parked descent keeps its state
     Arena A = arena_of(P, s.arena, g);
 
     if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) {
@@ -573,7 +590,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     const int lane = lane_id();
     azh_game_state s = P.gs[g];
     // while (root.all_edge_visits < global_visits) step();  (:522-525)
-    if (!(s.phase == 1 && (s.root_visits >= P.visits || P.force[g] != 0)))
+    if (s.phase != 2)
         return;
     Arena A = arena_of(P, s.arena, g);
     Arena B = arena_of(P, 1 - s.arena, g);
@@ -887,10 +904,31 @@ __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
 
 __global__ __launch_bounds__(WAVE) void k_backup(EngineParams P) { backup_game(P, blockIdx.x); }
 
-__global__ __launch_bounds__(WAVE) void k_advance(EngineParams P)
+// while (root.all_edge_visits < global_visits) step();  (:522-525): once the threshold is reached the move is due.
+// The game is only MARKED here (phase 2) and queued; the next select gives it no leaf, and the re-root
+// (advance_game) then runs from the queue in its own launch, beside the tower of the other games — a deep
+// subtree copy (one dependent round trip per tree level) no longer sits on every iteration's critical path.
+__device__ inline void mark_game(const EngineParams &P, int g)
+{
+    if (lane_id() != 0)
+        return;
+    const azh_game_state s = P.gs[g];
+    if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= P.visits || P.force[g] != 0)) {
+        P.gs[g].phase = 2;
+        P.adv_list[atomicAdd(P.adv_count, 1)] = g;
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void k_mark(EngineParams P) { mark_game(P, blockIdx.x); }
+
+__global__ __launch_bounds__(WAVE) void k_advance_list(EngineParams P)
 {
     __shared__ TreeLds L;
-    advance_game(P, blockIdx.x, L);
+    const int n = *P.adv_count;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        advance_game(P, P.adv_list[i], L);
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(WAVE) void k_tree(EngineParams P, int with_select)
@@ -899,7 +937,7 @@ __global__ __launch_bounds__(WAVE) void k_tree(EngineParams P, int with_select)
     const int g = blockIdx.x;
     backup_game(P, g);
     __syncthreads();
-    advance_game(P, g, L);
+    mark_game(P, g);
     __syncthreads();
     if (with_select)
         select_game(P, g, L);
@@ -952,6 +990,8 @@ struct azh_engine {
     azh_config cfg;
     EngineParams P;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // queued re-roots (k_advance_list) of the device loop
+    hipEvent_t ev_sel = nullptr, ev_adv = nullptr;
     std::vector<void *> allocs;
     float *d_feat = nullptr;
     float *d_sym_logits = nullptr, *d_sym_values = nullptr;  // AZH_FLAG_SYMMETRY_AVG scratch
@@ -1011,6 +1051,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     P.blockers = cfg->blockers;
     P.start_turn = cfg->start_turn;
     P.flags = cfg->flags;
+    P.select_budget = (int)cfg->select_budget;
 
     const size_t G = (size_t)P.G;
     // ring of finished-game records (64 KiB per slot between two drains)
@@ -1018,6 +1059,8 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     int rc = 0;
     rc |= dev_alloc(e, &P.gs, G);
     rc |= dev_alloc(e, &P.force, G);
+    rc |= dev_alloc(e, &P.adv_list, G);
+    rc |= dev_alloc(e, &P.adv_count, 1);
     rc |= dev_alloc(e, &P.path, G * P.path_cap);
     rc |= dev_alloc(e, &P.node_board, 2 * G * P.node_cap);
     rc |= dev_alloc(e, &P.node_info, 2 * G * P.node_cap);
@@ -1042,7 +1085,10 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
         azh_engine_destroy(e);
         return rc;
     }
-    if (hipStreamCreate(&e->stream) != hipSuccess || hipHostMalloc((void **)&e->h_count, sizeof(int)) != hipSuccess) {
+    if (hipStreamCreate(&e->stream) != hipSuccess || hipStreamCreate(&e->stream2) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_sel, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_adv, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_count, sizeof(int)) != hipSuccess) {
         azh_engine_destroy(e);
         return azh_fail(-4, "azh_engine_create: stream / pinned allocation failed");
     }
@@ -1073,6 +1119,12 @@ extern "C" void azh_engine_destroy(azh_engine *e)
         (void)hipFree(e->d_sym_values);
     if (e->h_count)
         (void)hipHostFree(e->h_count);
+    if (e->ev_sel)
+        (void)hipEventDestroy(e->ev_sel);
+    if (e->ev_adv)
+        (void)hipEventDestroy(e->ev_adv);
+    if (e->stream2)
+        (void)hipStreamDestroy(e->stream2);
     if (e->stream)
         (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1083,16 +1135,29 @@ extern "C" int azh_engine_edge_cap(const azh_engine *e) { return e ? e->P.edge_c
 
 static int enqueue_compact(azh_engine *e);
 
+constexpr int ADV_GRID = 256;
+
+// the queued re-roots, on `stream` (always after a select has passed over the queued games)
+static int enqueue_advance(azh_engine *e, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_advance_list, dim3(ADV_GRID), dim3(WAVE), 0, stream, e->P);
+    AZH_HIP(hipGetLastError());
+    AZH_HIP(hipMemsetAsync(e->P.adv_count, 0, sizeof(int), stream));
+    return 0;
+}
+
 static int enqueue_select(azh_engine *e)
 {
     hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
-    return enqueue_compact(e);
+    if (enqueue_compact(e))
+        return -1;
+    return enqueue_advance(e, e->stream);
 }
 
 static int enqueue_backup(azh_engine *e)
 {
     hipLaunchKernelGGL(k_backup, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
-    hipLaunchKernelGGL(k_advance, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
+    hipLaunchKernelGGL(k_mark, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -1207,6 +1272,15 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         return 0;
     hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
     if (enqueue_compact(e)) return -1;
+    // queued re-roots run on the side stream, under the tower that follows; the next tree launch waits for them
+    auto side_advance = [&]() -> int {
+        AZH_HIP(hipEventRecord(e->ev_sel, e->stream));
+        AZH_HIP(hipStreamWaitEvent(e->stream2, e->ev_sel, 0));
+        if (enqueue_advance(e, e->stream2)) return -1;
+        AZH_HIP(hipEventRecord(e->ev_adv, e->stream2));
+        return 0;
+    };
+    if (side_advance()) return -1;
     for (int it = 0; it < iterations; it++) {
         const bool rec = e->timing && e->ev_used + 4 <= e->events.size();
         hipEvent_t *ev = rec ? &e->events[e->ev_used] : nullptr;
@@ -1217,9 +1291,11 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         if (rc) return rc;
         if (rec) AZH_HIP(hipEventRecord(ev[2], e->stream));
         const int last = it + 1 == iterations;
+        AZH_HIP(hipStreamWaitEvent(e->stream, e->ev_adv, 0));
         hipLaunchKernelGGL(k_tree, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P, last ? 0 : 1);
         if (!last && enqueue_compact(e)) return -1;
         AZH_HIP(hipGetLastError());
+        if (!last && side_advance()) return -1;
         if (rec) {
             // ev[1]..ev[2] = tower; ev[2]..ev[3] = the tree phases (+ compaction) that follow it
             AZH_HIP(hipEventRecord(ev[3], e->stream));

@@ -41,7 +41,7 @@ class Config(ctypes.Structure):
                 ("dirichlet_alpha", ctypes.c_float), ("dirichlet_weight", ctypes.c_float),
                 ("start_turn", ctypes.c_int32), ("seed", ctypes.c_uint64), ("start_x", ctypes.c_uint64),
                 ("start_o", ctypes.c_uint64), ("blockers", ctypes.c_uint64),
-                ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint32), ("select_budget", ctypes.c_uint32)]
 
 
 class GameState(ctypes.Structure):

@@ -45,12 +45,13 @@ def parse_fen(fen):
 
 
 def make_config(games, visits, seed=DEFAULT_SEED, fen=START_FEN_SELFPLAY, max_plies=400, edges_per_node=96,
-                c_puct=1.0, dirichlet_alpha=0.15, dirichlet_weight=0.25, flags=0):
+                c_puct=1.0, dirichlet_alpha=0.15, dirichlet_weight=0.25, flags=0, select_budget=0):
     """Search constants default to cpp/self_play_client.cpp:31-34."""
     x, o, bl, turn = parse_fen(fen)
     return link.Config(games=games, visits=visits, max_plies=max_plies, edges_per_node=edges_per_node,
                        c_puct=c_puct, dirichlet_alpha=dirichlet_alpha, dirichlet_weight=dirichlet_weight,
-                       start_turn=turn, seed=seed, start_x=x, start_o=o, blockers=bl, flags=flags)
+                       start_turn=turn, seed=seed, start_x=x, start_o=o, blockers=bl, flags=flags,
+                       select_budget=select_budget)
 
 
 def process_index_from_path(path):

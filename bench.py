@@ -94,7 +94,8 @@ def target_leg(conv, bn, args, games=16384, steps=300, warmup=100):
     """BASELINE.json's north-star operating point (>= 10k concurrent games on one GPU, 400 sims/move) measured
     the same way as the headline, reported beside it (never as `value`)."""
     from ataxxzero_amd import model, selfplay
-    sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=args.dtype, seed=selfplay.DEFAULT_SEED + 77)
+    sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=args.dtype, seed=selfplay.DEFAULT_SEED + 77,
+                           select_budget=args.select_budget)
     def run(iters):
         done = 0
         while done < iters:
@@ -145,6 +146,10 @@ def main():
                          "(a fresh start has every game at ply 0 with an empty tree), followed by --phase-fill "
                          "iterations at full sims/move that regrow the trees; then the --warmup steps")
     ap.add_argument("--phase-fill", type=int, default=500)
+    ap.add_argument("--select-budget", type=int, default=48,
+                    help="tree levels per select launch and game (azh_config.select_budget; 0 = unlimited): deeper "
+                         "descents park and resume next iteration, so a launch does not last as long as the deepest "
+                         "line of the batch; every game still plays exactly the same search")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target-leg", action="store_true", help="skip the 16384-game leg reported beside the headline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -159,7 +164,8 @@ def main():
 
     conv, bn = model.random_init(args.blocks, 128, seed=1)
     sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
-                           seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank), streams=args.streams)
+                           seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank), streams=args.streams,
+                           select_budget=args.select_budget)
 
     def run(iters):
         done = 0
@@ -214,6 +220,7 @@ def main():
                                    "(per-GPU shard of BASELINE configs[2]; configs[1] at the metric's 400 sims)"
                                    % (args.games, args.visits, args.blocks, args.dtype),
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
+                       "select_budget": args.select_budget,
                        "setup": "games spread over all phases by %d untimed 16-sim iterations + %d at full sims, then "
                                 "the warm-up" % (args.phase_mix, args.phase_fill if args.phase_mix > 0 else 0),
                        "net": "%dx128" % args.blocks,

@@ -35,7 +35,7 @@ extern "C" {
 #define AZH_STAT_COUNT 16
 
 enum { AZH_DTYPE_F32 = 0, AZH_DTYPE_BF16 = 1, AZH_DTYPE_F16 = 2 };
-enum { AZH_LEAF_NONE = 0, AZH_LEAF_EVAL = 1, AZH_LEAF_TERMINAL = 2, AZH_LEAF_ROOT = 3 };
+enum { AZH_LEAF_NONE = 0, AZH_LEAF_EVAL = 1, AZH_LEAF_TERMINAL = 2, AZH_LEAF_ROOT = 3, AZH_LEAF_DESCENT = 4 };
 
 /* ------------------------------------------------------------------ errors */
 const char *azh_last_error(void);
@@ -130,7 +130,11 @@ typedef struct {
     uint64_t seed;
     uint64_t start_x, start_o, blockers; /* STARTING_GAME_POSITION (:23) */
     uint32_t flags;          /* AZH_FLAG_*; 0 = the C++ self-play generator's behaviour */
-    uint32_t reserved;
+    uint32_t select_budget;  /* 0 = every descent finishes inside one select; k > 0 = at most k tree levels per
+                                select: a deeper descent parks (AZH_LEAF_DESCENT, no leaf this iteration) and
+                                resumes next iteration where it stopped.  A parked game's tree does not change in
+                                between, so each game plays bit for bit what it plays with budget 0; the launch no
+                                longer lasts as long as the deepest descent of the batch */
 } azh_config;
 
 /* Behaviour switches that turn the self-play search into the arena search, i.e. the

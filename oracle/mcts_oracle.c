@@ -184,7 +184,14 @@ static void select_game(orc_engine *e, int g)
     orc_game_state *s = &e->gs[g];
     uint64_t *st = e->stats + (size_t)g * ORC_STAT_COUNT;
     int a = s->arena;
-    s->path_len = 0;
+    const int resume = s->leaf_kind == ORC_LEAF_DESCENT;
+    if (!resume)
+        s->path_len = 0;
+    if (s->phase == ORC_PHASE_ADVANCING) {
+        s->leaf_kind = ORC_LEAF_NONE;
+        s->leaf_node = 0;
+        return; /* orc_engine_select plays the move after the leaf pass */
+    }
     if (s->phase == ORC_PHASE_ROOT_EVAL) {
         if ((e->cfg.flags & ORC_FLAG_TWO_NETS) && (NI(e, a, g)[1] & 0xFFFFu) == 1) {
             /* arena: a single legal move is played without search (uai_ringmaster.py:114-116) */
@@ -202,10 +209,20 @@ static void select_game(orc_engine *e, int g)
     uint32_t *ni = NI(e, a, g);
     uint32_t *ed = ED(e, a, g);
     int32_t *path = e->path + (size_t)g * e->path_cap;
-    uint32_t node = 0;
-    int depth = 0;
-    st[ORC_STAT_STEPS]++;
+    uint32_t node = resume ? (uint32_t)s->leaf_node : 0;
+    int depth = resume ? s->path_len : 0;
+    int levels_done = 0;
+    if (!resume)
+        st[ORC_STAT_STEPS]++;
     for (;;) {
+        if (e->cfg.select_budget && levels_done == (int)e->cfg.select_budget) {
+            /* park the descent at this node; the evaluator gets no leaf from this game this iteration */
+            s->leaf_kind = ORC_LEAF_DESCENT;
+            s->leaf_node = (int)node;
+            s->path_len = depth;
+            return;
+        }
+        levels_done++;
         uint32_t first = ni[4 * node + 0];
         int M = (int)(ni[4 * node + 1] & 0xFFFFu);
         int result = (int)(ni[4 * node + 1] >> 16);
@@ -278,6 +295,8 @@ static void select_game(orc_engine *e, int g)
     }
 }
 
+static void advance_game(orc_engine *e, int g);
+
 int orc_engine_select(orc_engine *e, int32_t *need_eval)
 {
     int count = 0;
@@ -291,6 +310,9 @@ int orc_engine_select(orc_engine *e, int32_t *need_eval)
         if (need_eval) need_eval[g] = need;
         count += need != 0;
     }
+    for (int g = 0; g < e->G; g++)
+        if (e->gs[g].phase == ORC_PHASE_ADVANCING)
+            advance_game(e, g);
     return count;
 }
 
@@ -615,11 +637,12 @@ void orc_engine_backup(orc_engine *e, const float *logits, const float *values)
         default:
             break;
         }
+        if (s->leaf_kind == ORC_LEAF_DESCENT)
+            continue; /* parked descent: nothing to back up, and the tree must stay as it is */
         s->leaf_kind = ORC_LEAF_NONE;
-        /* while (root.all_edge_visits < global_visits) step(); (:522-525) */
-        while (s->phase == ORC_PHASE_SEARCH && (s->root_visits >= e->cfg.visits || e->force[g])) {
-            advance_game(e, g);
-        }
+        /* while (root.all_edge_visits < global_visits) step(); (:522-525): the move is due */
+        if (s->phase == ORC_PHASE_SEARCH && (s->root_visits >= e->cfg.visits || e->force[g]))
+            s->phase = ORC_PHASE_ADVANCING;
     }
 }
 

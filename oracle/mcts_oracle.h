@@ -35,7 +35,11 @@ typedef struct {
     uint64_t seed;
     uint64_t start_x, start_o, blockers; /* STARTING_GAME_POSITION (:23) */
     uint32_t flags;           /* ORC_FLAG_*: the arena variants of the search (engine.py) */
-    uint32_t reserved;
+    uint32_t select_budget;   /* 0 = a descent always finishes within one orc_engine_select; k > 0 = at most k tree
+                                 levels per call: a longer descent parks (ORC_LEAF_DESCENT, no leaf this
+                                 iteration) and resumes at the next call from the node it stopped at.  The tree of
+                                 a parked game does not change in between, so every game plays bit for bit what it
+                                 plays with budget 0: only the iteration in which a leaf reaches the evaluator moves */
 } orc_config;
 
 enum {
@@ -44,8 +48,11 @@ enum {
     ORC_FLAG_ONE_RANDOM_MOVE = 64 /* the ONE_RANDOM_MOVE build of the client (cpp/self_play_client.cpp:515-552) */
 };
 
-enum { ORC_LEAF_NONE = 0, ORC_LEAF_EVAL = 1, ORC_LEAF_TERMINAL = 2, ORC_LEAF_ROOT = 3 };
-enum { ORC_PHASE_ROOT_EVAL = 0, ORC_PHASE_SEARCH = 1 };
+enum { ORC_LEAF_NONE = 0, ORC_LEAF_EVAL = 1, ORC_LEAF_TERMINAL = 2, ORC_LEAF_ROOT = 3, ORC_LEAF_DESCENT = 4 };
+/* ORC_PHASE_ADVANCING: the move is due (root visits reached the threshold at the last backup).  The next select
+ * gives the game no leaf and then plays the move (sampling, record, re-root): in the HIP engine the re-root runs
+ * in its own launch beside the evaluator, so the iteration structure is part of the engine/oracle contract. */
+enum { ORC_PHASE_ROOT_EVAL = 0, ORC_PHASE_SEARCH = 1, ORC_PHASE_ADVANCING = 2 };
 
 /* per-game scalar state, same field order as the HIP engine's snapshot */
 typedef struct {

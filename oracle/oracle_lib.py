@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 STAT_NAMES = ["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
               "edge_overflow", "reroot_nodes", "reroot_edges"]
 STAT_COUNT = 16
-LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT = 0, 1, 2, 3
+LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT, LEAF_DESCENT = 0, 1, 2, 3, 4
 FLAG_NO_REUSE, FLAG_TIE_FIRST, FLAG_PY_POSTERIOR, FLAG_SAMPLE_POW5, FLAG_KEEP_UNFINISHED, FLAG_TWO_NETS = 1, 2, 4, 8, 16, 32
 FLAG_ARENA = 63
 FLAG_ONE_RANDOM_MOVE = 64
@@ -31,7 +31,7 @@ class Config(ctypes.Structure):
                 ("dirichlet_alpha", ctypes.c_float), ("dirichlet_weight", ctypes.c_float),
                 ("start_turn", ctypes.c_int32), ("seed", ctypes.c_uint64), ("start_x", ctypes.c_uint64),
                 ("start_o", ctypes.c_uint64), ("blockers", ctypes.c_uint64),
-                ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint32), ("select_budget", ctypes.c_uint32)]
 
 
 class GameState(ctypes.Structure):
@@ -155,11 +155,12 @@ START_FEN_PLAIN = "x5o/7/7/7/7/7/o5x x"               # ataxx_rules.py:44-50
 
 
 def make_config(games, visits, seed=20260101, fen_str=START_FEN_SELFPLAY, max_plies=400,
-                edges_per_node=96, c_puct=1.0, alpha=0.15, weight=0.25, flags=0):
+                edges_per_node=96, c_puct=1.0, alpha=0.15, weight=0.25, flags=0, select_budget=0):
     p = pos_from_fen(fen_str)
     return Config(games=games, visits=visits, max_plies=max_plies, edges_per_node=edges_per_node,
                   c_puct=c_puct, dirichlet_alpha=alpha, dirichlet_weight=weight, start_turn=p.turn,
-                  seed=seed, start_x=p.pieces[0], start_o=p.pieces[1], blockers=p.blockers, flags=flags)
+                  seed=seed, start_x=p.pieces[0], start_o=p.pieces[1], blockers=p.blockers, flags=flags,
+                  select_budget=select_budget)
 
 
 def parse_game_record(buf):

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 def make_pair(games, visits, max_plies=400, edges_per_node=96, seed=77, fen=orc.START_FEN_SELFPLAY, weight=0.25,
-              flags=0):
+              flags=0, select_budget=0):
     ocfg = orc.make_config(games, visits, seed=seed, fen_str=fen, max_plies=max_plies,
-                           edges_per_node=edges_per_node, weight=weight, flags=flags)
+                           edges_per_node=edges_per_node, weight=weight, flags=flags, select_budget=select_budget)
     gcfg = link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_})
     return orc.Engine(ocfg), link.Engine(gcfg)
 
@@ -188,3 +188,37 @@ def test_symmetry_averaging_flag_in_the_device_loop_equals_host_evaluated_search
         for a, b in zip(dev.tree(g), host.tree(g)):
             assert a.shape == b.shape and (a == b).all()
     assert dev.stats()["plies"] == host.stats()["plies"] > 9
+
+
+def test_parked_descents_match_oracle_and_leave_every_game_unchanged():
+    # select_budget: a descent deeper than the budget parks and resumes next iteration.  Lockstep parity with the
+    # oracle's same rule, and the games written are exactly the games of the unbudgeted engine.
+    oe, ge = make_pair(games=16, visits=12, max_plies=300, seed=21, select_budget=2)
+    o_games, g_lines = run_lockstep(oe, ge, 3000, check_every=13)
+    so, sg = oe.stats(), ge.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    assert len(g_lines) >= 3
+    parked = 0
+    for _ in range(30):
+        ge.select()
+        parked += sum(ge.game_state(g).leaf_kind == 4 for g in range(16))
+        need, lb = ge.leaves()
+        lg, v = synthetic_evals(lb)
+        ge.set_evals(lg, v)
+        ge.backup()
+    assert parked > 0  # the budget really bites
+    # same seeds without a budget: the same games, bit for bit (only the iteration they finish in differs)
+    _, ge0 = make_pair(games=16, visits=12, max_plies=300, seed=21)
+    want = len(g_lines)
+    lines0 = []
+    for _ in range(4000):
+        ge0.select()
+        need, lb = ge0.leaves()
+        lg, v = synthetic_evals(lb)
+        ge0.set_evals(lg, v)
+        ge0.backup()
+        lines0 += ge0.drain_json()
+        if len(lines0) >= want + 16:
+            break
+    assert set(g_lines) <= set(lines0)

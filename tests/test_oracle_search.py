@@ -118,3 +118,17 @@ def test_one_random_move_variant():
     e2 = orc.Engine(cfg)
     games2 = run(e2, 2600, null_eval)
     assert [g["entry"] for g in games2] == [g["entry"] for g in games]
+
+
+def test_select_budget_changes_timing_not_games():
+    # parked descents (select_budget) resume on an unchanged tree: per game the same search, the same record
+    def play(budget, iters):
+        e = orc.Engine(orc.make_config(games=8, visits=12, seed=12, max_plies=300, select_budget=budget))
+        return {g["uid"]: g["entry"] for g in run(e, iters, synthetic_evals)}, e
+    base, e0 = play(0, 6000)
+    slow, e1 = play(2, 12000)
+    common = set(base) & set(slow)
+    assert len(common) >= 4
+    for uid in common:
+        assert base[uid] == slow[uid]
+    assert e1.stats()["steps"] < 12000 * 8  # some iterations were spent parked
