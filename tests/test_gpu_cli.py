@@ -268,3 +268,23 @@ def test_generate_games_supervised_with_own_uai_engine_as_teacher(tmp_path):
     entries = training.load_entries([out])
     f, pol, val = training.get_sample_from_entries(entries)
     assert abs(pol.sum() - 1.0) < 1e-6 and val[0] in (1, -1)
+
+
+def test_accelerated_generate_games_extension_flags(tmp_path):
+    """--one-random-move (the client's ONE_RANDOM_MOVE build as a switch), --select-budget, --streams 2, --max-seconds."""
+    conv, bn = model.random_init(1, 128, seed=5)
+    net_path = str(tmp_path / "model-002.npy")
+    model.save_model(net_path, conv, bn)
+    games_path = str(tmp_path / "model-002-0.json")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "accelerated_generate_games.py"), "--network", net_path,
+                          "--output-games", games_path, "--visits", "6", "--buffer-size", "48", "--one-random-move",
+                          "--select-budget", "3", "--streams", "2", "--max-seconds", "12"],
+                         cwd=ROOT, capture_output=True, timeout=240)
+    assert res.returncode == 0, res.stdout.decode()[-2000:] + res.stderr.decode()[-2000:]
+    lines = [l for l in open(games_path) if l.strip()]
+    assert len(lines) >= 10
+    for line in lines[:12]:
+        entry = json.loads(line)
+        assert list(entry) == ["boards", "dists", "moves", "random_ply", "result"]
+        assert 0 <= entry["random_ply"] < 120
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
