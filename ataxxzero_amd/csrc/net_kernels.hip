@@ -579,6 +579,11 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
 // 0/1 take channels 0-63, waves 2/3 channels 64-127; even waves take cell tiles 0-4, odd 5-9.
 // A fragment: lane l holds W[oc = 16T + (l & 15)][k = 8 (l >> 4) + j]; B fragment: lane l holds
 // act[cell = 16t + (l & 15)][k = 8 (l >> 4) + j]; D: lane l holds oc = 4 (l >> 4) + reg of cell l & 15.
+#ifndef AZH_RING2
+#define AZH_RING2 2
+#endif
+constexpr int RING2 = AZH_RING2;  // A-fragment ring depth of variant 2 (steps of prefetch distance)
+
 template <int DT> struct Mfma16;
 template <> struct Mfma16<AZH_DTYPE_BF16> {
     __device__ static f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
@@ -630,7 +635,7 @@ template <int CHF> __device__ constexpr bool skip_pair(int ct, int dyi)
 template <int DT, int KS, int CHF, bool STAMP>
 __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, bool skip,
                                    const typename Traits<DT>::afrag *__restrict__ wp,
-                                   typename Traits<DT>::afrag (&a)[2][4], f32x16 &sh, const float *__restrict__ shift_next,
+                                   typename Traits<DT>::afrag (&a)[RING2][4], f32x16 &sh, const float *__restrict__ shift_next,
                                    const int (&vmask)[Geo2::TPW], int wave, int lane, unsigned long long *st)
 {
     typedef Traits<DT> Tr;
@@ -638,6 +643,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     typedef typename Tr::afrag afrag;
     constexpr int TPW = G::TPW;
     constexpr int TOTAL = 9 * KS;
+    static_assert((3 * KS) % RING2 == 0 || KS == 1, "ring phase must be compile-time inside a dx row");
     const int r = lane & 15, kg = lane >> 4;
     const int oh = wave >> 1;
     // accumulators [A tile][cell tile], started at the batch-norm shift (+ residual input)
@@ -714,12 +720,14 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     afrag b[2][TPW];
     int cur[TPW], nxt[TPW];
     // one dx row of taps = 3 KS steps, straight-line: step j consumes tap dyi = j / KS, k-step j % KS
-    auto dx_row = [&](int dxi, auto par0_tag) {
+    auto dx_row = [&](int dxi, auto par0_tag, auto ring0_tag) {
         constexpr int par0 = decltype(par0_tag)::value;  // buffer parity of the row's first step
+        constexpr int ring0 = decltype(ring0_tag)::value;  // A ring slot of the row's first step
         static_for<0, 3 * KS>([&](auto j_tag) {
             constexpr int j = decltype(j_tag)::value;
             constexpr int dyi = j / KS, ks = j % KS;
             constexpr int par = (par0 + j) & 1;
+            constexpr int rs = (ring0 + j) % RING2;
             constexpr int j1 = j + 1;
             constexpr int dyi1 = (j1 / KS) % 3, ks1 = j1 % KS;
             const int s = (3 * dxi + dyi) * KS + ks;
@@ -738,9 +746,9 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
                 static_for<0, TPW>([&](auto ct_tag) {
                     constexpr int ct = decltype(ct_tag)::value;
                     if constexpr (!skip_pair<CHF>(ct, dyi))
-                        acc[t][ct] = Mfma16<DT>::mfma(a[par][t], b[par][ct], acc[t][ct]);
+                        acc[t][ct] = Mfma16<DT>::mfma(a[rs][t], b[par][ct], acc[t][ct]);
                 });
-            load_a(a[par], s + 2);
+            load_a(a[rs], s + RING2);
             if constexpr (ks1 == 0) {
 #pragma unroll
                 for (int ct = 0; ct < TPW; ct++)
@@ -757,21 +765,27 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     if constexpr ((3 * KS) % 2 != 0) {
         static_for<0, 3>([&](auto d_tag) {
             constexpr int d = decltype(d_tag)::value;
-            dx_row(d, IC<(3 * KS * d) & 1>());
+            dx_row(d, IC<(3 * KS * d) & 1>(), IC<(3 * KS * d) % RING2>());
         });
     } else {
         for (int dxi = 0; dxi < 3; dxi++)
-            dx_row(dxi, IC<0>());
+            dx_row(dxi, IC<0>(), IC<0>());
     }
     if constexpr (STAMP) st[1] = stamp_now();
     fetch_shift();
-    if constexpr (TOTAL % 2 != 0) {  // ring slots hold steps TOTAL, TOTAL+1 in swapped order
+    if constexpr (TOTAL % RING2 != 0) {  // rotate so that slot i holds step TOTAL + i of the packed stream
+        constexpr int sh_ = TOTAL % RING2;
+        afrag tmp[RING2][4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const afrag tmp = a[0][t];
-            a[0][t] = a[1][t];
-            a[1][t] = tmp;
-        }
+        for (int i = 0; i < RING2; i++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                tmp[i][t] = a[(i + sh_) % RING2][t];
+#pragma unroll
+        for (int i = 0; i < RING2; i++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                a[i][t] = tmp[i][t];
     }
     // epilogue: relu, convert, write 4 channels (8 bytes) per (A tile, cell tile)
 #pragma unroll
@@ -829,9 +843,9 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
     const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w2);
     const size_t l0 = (size_t)9 * G::KS_IN * 8 * 64, lf = (size_t)9 * G::KS_FULL * 8 * 64;
     const int oh = wave >> 1, kg = lane >> 4;
-    afrag aring[2][4];
+    afrag aring[RING2][4];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < RING2; i++)
 #pragma unroll
         for (int t = 0; t < 4; t++)
             aring[i][t] = wp[((size_t)i * 8 + 4 * oh + t) * 64 + lane];
@@ -1083,7 +1097,7 @@ static int net_pack(azh_net *net, int dt)
         pack_conv16(p, sc, 4, 9, 1, 8, F, dt, cw2);
         for (int l = 0; l < 2 * B; l++)
             pack_conv16(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, sc + (size_t)(l + 1) * F, F, 9, 4, 8, F, dt, cw2);
-        cw2.resize(cw2.size() + (size_t)2 * 8 * 64 * 8, 0);  // the A ring reads two steps past the last layer
+        cw2.resize(cw2.size() + (size_t)RING2 * 8 * 64 * 8, 0);  // the A ring reads RING2 steps past the last layer
         pack_conv16(head.data(), nullptr, F, 1, 4, 2, 32, dt, hw2);
         if (upload(cw2.data(), cw2.size() * 2, &net->bufs[dt].conv_w2)) return -1;
         if (upload(hw2.data(), hw2.size() * 2, &net->bufs[dt].head_w2)) return -1;

@@ -288,3 +288,23 @@ def test_accelerated_generate_games_extension_flags(tmp_path):
         assert list(entry) == ["boards", "dists", "moves", "random_ply", "result"]
         assert 0 <= entry["random_ply"] < 120
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's keys, the roofline and the cpu_baseline objects."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--games", "96", "--visits", "8", "--blocks", "1",
+                          "--steps", "30", "--warmup", "10", "--phase-mix", "40", "--phase-fill", "10", "--chunk", "10",
+                          "--cpu-seconds", "1.5", "--no-target-leg"], cwd=ROOT, capture_output=True, timeout=400)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 10 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["tree_only_value"] > c["value"]
