@@ -46,8 +46,11 @@ def build(force=False, verbose=False):
         if os.path.exists(LIB):
             return LIB  # prebuilt library shipped with the snapshot
         raise RuntimeError("hipcc not found and no prebuilt %s" % LIB)
-    os.makedirs(OBJ, exist_ok=True)
     deps = _deps()
+    sources = [os.path.join(CSRC, src) for src, _ in UNITS]
+    if not force and not _stale(LIB, sources + deps):
+        return LIB  # up to date (the object directory does not travel with the snapshot; the library does)
+    os.makedirs(OBJ, exist_ok=True)
     objs, procs = [], []
     for src, extra in UNITS:
         s = os.path.join(CSRC, src)
