@@ -613,11 +613,28 @@ struct Geo2 {
     __device__ static int vcell_off(int c) { return (c / 40) * CS + 310 * UB + (c % 40) * 4; }
 };
 
-// Cells of a workgroup are numbered c = 21 y + 7 board + x (the rows of the three boards interleaved): a
-// neighbour is still one uniform offset away (dx + 21 dy), and the 16-cell tiles 0 (cells 0..15: y = 0) and
-// 8, 9 (cells 128..146: y = 6) hold cells of one board edge only, so the taps that look past that edge are
-// all-zero for the whole tile and are skipped at compile time (B loads and MFMAs): 9 of the 90 (tile, tap)
-// pairs per layer.  The FLOP count reported for the kernel stays the padded-tap figure.
+// Cells of a workgroup are numbered c = 21 y + 7 board + x (the rows of the three boards interleaved), and LDS slot =
+// cell, so a neighbour is one uniform offset away (dx + 21 dy).  WHICH 16 cells form an MFMA cell tile is free, as long
+// as the 16 lanes of a tile keep distinct slots mod 16 (the bank rule of ds_read_b128's 16-lane groups): lane r of a
+// tile always holds a cell with c % 16 == r.  Four tiles are filled with cells of one board edge each — y = 0, y = 6
+// (wave half 0) and x = 0, x = 6 (wave half 1), 16 cells apiece — so the three taps that look past that edge are
+// all-zero for the whole tile and are dropped at compile time (B loads and MFMAs): 12 of the 90 (tile, tap) pairs per
+// layer, 6 per wave half.  The other six tiles take the k-th remaining cell of every residue class.  Generated by
+// tools/tower_tile_table.py; entries >= 0x100 are empty lanes (pseudo cell = lane, never valid).
+// The FLOP count reported for the kernel stays the padded-tap figure.
+__device__ const unsigned short TILE_CELL[10][16] = {
+    {0x010, 0x001, 0x002, 0x003, 0x004, 0x005, 0x006, 0x007, 0x008, 0x009, 0x00a, 0x00b, 0x00c, 0x00d, 0x00e, 0x00f},
+    {0x080, 0x081, 0x082, 0x083, 0x084, 0x085, 0x086, 0x087, 0x088, 0x089, 0x08a, 0x08b, 0x08c, 0x08d, 0x08e, 0x07f},
+    {0x000, 0x011, 0x012, 0x013, 0x024, 0x025, 0x016, 0x017, 0x018, 0x019, 0x01a, 0x02b, 0x02c, 0x01d, 0x01e, 0x01f},
+    {0x020, 0x021, 0x032, 0x033, 0x034, 0x035, 0x026, 0x027, 0x028, 0x039, 0x03a, 0x03b, 0x03c, 0x02d, 0x02e, 0x02f},
+    {0x040, 0x041, 0x042, 0x043, 0x044, 0x055, 0x036, 0x047, 0x048, 0x049, 0x04a, 0x04b, 0x05c, 0x03d, 0x04e, 0x04f},
+    {0x070, 0x031, 0x062, 0x023, 0x054, 0x015, 0x046, 0x077, 0x038, 0x069, 0x02a, 0x05b, 0x01c, 0x04d, 0x07e, 0x03f},
+    {0x030, 0x061, 0x022, 0x053, 0x014, 0x045, 0x076, 0x037, 0x068, 0x029, 0x05a, 0x01b, 0x04c, 0x07d, 0x03e, 0x06f},
+    {0x050, 0x051, 0x052, 0x063, 0x064, 0x065, 0x056, 0x057, 0x058, 0x059, 0x06a, 0x06b, 0x06c, 0x05d, 0x05e, 0x05f},
+    {0x060, 0x071, 0x072, 0x073, 0x074, 0x075, 0x066, 0x067, 0x078, 0x079, 0x07a, 0x07b, 0x07c, 0x06d, 0x06e, 0x08f},
+    {0x090, 0x091, 0x092, 0x103, 0x104, 0x105, 0x106, 0x107, 0x108, 0x109, 0x10a, 0x10b, 0x10c, 0x10d, 0x10e, 0x10f},
+};
+
 __device__ inline void cell_xy(int c, int &bl, int &x, int &y)
 {
     y = c / 21;
@@ -626,25 +643,27 @@ __device__ inline void cell_xy(int c, int &bl, int &x, int &y)
     x = r - 7 * bl;
 }
 
-// CHF = cell half of the wave (tiles 5 CHF .. 5 CHF + 4); dyi = tap % 3 (dy + 1)
-template <int CHF> __device__ constexpr bool skip_pair(int ct, int dyi)
-{
-    return CHF == 0 ? (ct == 0 && dyi == 0) : ((ct == 3 || ct == 4) && dyi == 2);
-}
+// The taps of a layer are walked as three rows of three: wave half 0 walks dx in the (run-time) row loop and dy inside
+// the unrolled row, wave half 1 the other way round, so that for both halves "tile 0 skips inner index 0, tile 1 skips
+// inner index 2" is a compile-time fact.
+__device__ constexpr bool skip_pair(int ct, int inner) { return (ct == 0 && inner == 0) || (ct == 1 && inner == 2); }
 
 template <int DT, int KS, int CHF, bool STAMP>
 __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, bool skip,
                                    const typename Traits<DT>::afrag *__restrict__ wp,
                                    typename Traits<DT>::afrag (&a)[RING2][4], f32x16 &sh, const float *__restrict__ shift_next,
-                                   const int (&vmask)[Geo2::TPW], int wave, int lane, unsigned long long *st)
+                                   const int (&vmask)[Geo2::TPW], const int (&cellv)[Geo2::TPW], int wave, int lane,
+                                   unsigned long long *st)
 {
     typedef Traits<DT> Tr;
     typedef Geo2 G;
     typedef typename Tr::afrag afrag;
     constexpr int TPW = G::TPW;
     constexpr int TOTAL = 9 * KS;
-    static_assert((3 * KS) % RING2 == 0 || KS == 1, "ring phase must be compile-time inside a dx row");
-    const int r = lane & 15, kg = lane >> 4;
+    constexpr int ROW = 3 * KS;  // steps per row of three taps
+    static_assert(ROW % RING2 == 0 || KS == 1, "ring phase must be compile-time inside a row");
+    static_assert(RING2 <= ROW, "the ring prefetch reaches at most one row ahead");
+    const int kg = lane >> 4;
     const int oh = wave >> 1;
     // accumulators [A tile][cell tile], started at the batch-norm shift (+ residual input)
     f32x4 acc[4][TPW];
@@ -662,8 +681,8 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         typename Tr::quad sk[4][TPW];
 #pragma unroll
         for (int ct = 0; ct < TPW; ct++) {
-            const int cell = 16 * (TPW * CHF + ct) + r;
-            const int slot = cell < G::NC ? G::real_slot(out_img, cell) : G::zero_slot(out_img, cell);
+            const int cell = cellv[ct] & 0xFF;
+            const int slot = (cellv[ct] & 0x100) ? G::zero_slot(out_img, cell) : G::real_slot(out_img, cell);
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 sk[t][ct] = *reinterpret_cast<const typename Tr::quad *>(lds + G::ch_off(slot, 64 * oh + 16 * t + 4 * kg));
@@ -686,7 +705,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         }
     };
 
-    // A fragments of step s: [s][oc tile 8][lane][8 elements]; this wave reads tiles 4*oh .. 4*oh+3
+    // A fragments of packed step s = tap * KS + ks: [s][oc tile 8][lane][8 elements]; this wave reads tiles 4*oh .. 4*oh+3
     const char *wbase = reinterpret_cast<const char *>(wp) + oh * 4096;
     const unsigned lane_off = (unsigned)(lane * sizeof(afrag));
     auto load_a = [&](afrag (&dst)[4], int step) {
@@ -695,60 +714,70 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         for (int t = 0; t < 4; t++)
             dst[t] = *reinterpret_cast<const afrag *>(p + t * 1024 + lane_off);
     };
-    // byte offsets of this lane's B fragments for tap (dxi, dyi); skipped pairs are left alone
-    auto rows_for = [&](int dxi, auto dyi_tag, int (&dst)[TPW]) {
-        constexpr int dyi = decltype(dyi_tag)::value;
-        const int tap = 3 * dxi + dyi;
-        const int drow = (dxi - 1) + 21 * (dyi - 1);
+    // (row o, inner i) -> tap = 3 dxi + dyi
+    auto tap_of = [&](int o, int i) { return CHF == 0 ? 3 * o + i : 3 * i + o; };
+    // packed step of walk position (row o, step j of the row); positions past the layer continue into the next
+    // layer's stream, whose first KS steps are tap 0 in either walk
+    auto step_of = [&](int o, int j) {
+        if (j >= ROW) {
+            j -= ROW;
+            o += 1;
+        }
+        return o < 3 ? tap_of(o, j / KS) * KS + j % KS : TOTAL + j;
+    };
+    // byte offsets of this lane's B fragments for the tap at (row o, inner i); skipped pairs are left alone
+    auto rows_for = [&](int o, auto i_tag, int (&dst)[TPW]) {
+        constexpr int i = decltype(i_tag)::value;
+        const int tap = tap_of(o, i);
+        const int drow = CHF == 0 ? (o - 1) + 21 * (i - 1) : (i - 1) + 21 * (o - 1);
         static_for<0, TPW>([&](auto ct_tag) {
             constexpr int ct = decltype(ct_tag)::value;
-            if constexpr (!skip_pair<CHF>(ct, dyi)) {
-                const int c = 16 * (TPW * CHF + ct) + r + drow;
+            if constexpr (!skip_pair(ct, i)) {
+                const int c = (cellv[ct] & 0xFF) + drow;
                 const int slot = ((vmask[ct] >> tap) & 1) ? G::real_slot(in_img, c) : G::zero_slot(in_img, c);
                 dst[ct] = kg * G::CS + slot * G::UB;
             }
         });
     };
-    auto load_b = [&](afrag (&bf)[TPW], const int (&rows)[TPW], int ks, auto dyi_tag) {
-        constexpr int dyi = decltype(dyi_tag)::value;
+    auto load_b = [&](afrag (&bf)[TPW], const int (&rows)[TPW], int ks, auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
         static_for<0, TPW>([&](auto ct_tag) {
             constexpr int ct = decltype(ct_tag)::value;
-            if constexpr (!skip_pair<CHF>(ct, dyi))
+            if constexpr (!skip_pair(ct, i))
                 bf[ct] = *reinterpret_cast<const afrag *>(lds + rows[ct] + ks * (4 * G::CS));
         });
     };
     afrag b[2][TPW];
     int cur[TPW], nxt[TPW];
-    // one dx row of taps = 3 KS steps, straight-line: step j consumes tap dyi = j / KS, k-step j % KS
-    auto dx_row = [&](int dxi, auto par0_tag, auto ring0_tag) {
-        constexpr int par0 = decltype(par0_tag)::value;  // buffer parity of the row's first step
+    // one row of three taps = 3 KS steps, straight-line: step j consumes inner tap j / KS, k-step j % KS
+    auto tap_row = [&](int o, auto par0_tag, auto ring0_tag) {
+        constexpr int par0 = decltype(par0_tag)::value;    // B buffer parity of the row's first step
         constexpr int ring0 = decltype(ring0_tag)::value;  // A ring slot of the row's first step
-        static_for<0, 3 * KS>([&](auto j_tag) {
+        static_for<0, ROW>([&](auto j_tag) {
             constexpr int j = decltype(j_tag)::value;
-            constexpr int dyi = j / KS, ks = j % KS;
+            constexpr int i = j / KS, ks = j % KS;
             constexpr int par = (par0 + j) & 1;
             constexpr int rs = (ring0 + j) % RING2;
             constexpr int j1 = j + 1;
-            constexpr int dyi1 = (j1 / KS) % 3, ks1 = j1 % KS;
-            const int s = (3 * dxi + dyi) * KS + ks;
-            if constexpr (ks == 0) {  // offsets of the tap after this one (it may belong to the next dx row)
-                const int dx1 = dyi == 2 ? (dxi < 2 ? dxi + 1 : 2) : dxi;
-                rows_for(dx1, IC<(dyi + 1) % 3>(), nxt);
+            constexpr int i1 = (j1 / KS) % 3, ks1 = j1 % KS;
+            if constexpr (ks == 0) {  // offsets of the tap after this one (it may belong to the next row)
+                const int o1 = i == 2 ? (o < 2 ? o + 1 : 2) : o;
+                rows_for(o1, IC<(i + 1) % 3>(), nxt);
             }
-            // prefetch the B fragments of step s + 1
+            // prefetch the B fragments of the next step
             if constexpr (ks1 == 0)
-                load_b(b[par ^ 1], nxt, 0, IC<dyi1>());
+                load_b(b[par ^ 1], nxt, 0, IC<i1>());
             else
-                load_b(b[par ^ 1], cur, ks1, IC<dyi1>());
+                load_b(b[par ^ 1], cur, ks1, IC<i1>());
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 static_for<0, TPW>([&](auto ct_tag) {
                     constexpr int ct = decltype(ct_tag)::value;
-                    if constexpr (!skip_pair<CHF>(ct, dyi))
+                    if constexpr (!skip_pair(ct, i))
                         acc[t][ct] = Mfma16<DT>::mfma(a[rs][t], b[par][ct], acc[t][ct]);
                 });
-            load_a(a[rs], s + RING2);
+            load_a(a[rs], step_of(o, j + RING2));
             if constexpr (ks1 == 0) {
 #pragma unroll
                 for (int ct = 0; ct < TPW; ct++)
@@ -762,18 +791,18 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         nxt[ct] = cur[ct];
     load_b(b[0], cur, 0, IC<0>());
     if constexpr (STAMP) st[0] = stamp_now();
-    if constexpr ((3 * KS) % 2 != 0) {
+    if constexpr (ROW % 2 != 0 || ROW % RING2 != 0) {
         static_for<0, 3>([&](auto d_tag) {
             constexpr int d = decltype(d_tag)::value;
-            dx_row(d, IC<(3 * KS * d) & 1>(), IC<(3 * KS * d) % RING2>());
+            tap_row(d, IC<(ROW * d) & 1>(), IC<(ROW * d) % RING2>());
         });
     } else {
-        for (int dxi = 0; dxi < 3; dxi++)
-            dx_row(dxi, IC<0>(), IC<0>());
+        for (int o = 0; o < 3; o++)
+            tap_row(o, IC<0>(), IC<0>());
     }
     if constexpr (STAMP) st[1] = stamp_now();
     fetch_shift();
-    if constexpr (TOTAL % RING2 != 0) {  // rotate so that slot i holds step TOTAL + i of the packed stream
+    if constexpr (TOTAL % RING2 != 0) {  // rotate so that slot i holds walk position TOTAL + i (next layer's step i)
         constexpr int sh_ = TOTAL % RING2;
         afrag tmp[RING2][4];
 #pragma unroll
@@ -790,8 +819,8 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     // epilogue: relu, convert, write 4 channels (8 bytes) per (A tile, cell tile)
 #pragma unroll
     for (int ct = 0; ct < TPW; ct++) {
-        const int cell = 16 * (TPW * CHF + ct) + r;
-        if (cell < G::NC) {
+        if (!(cellv[ct] & 0x100)) {
+            const int cell = cellv[ct];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 float v[4];
@@ -821,16 +850,17 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
     typedef Traits<DT> Tr;
     typedef Geo2 G;
     typedef typename Tr::afrag afrag;
-    int vmask[G::TPW];
+    int vmask[G::TPW], cellv[G::TPW];
     {
         const int r = lane & 15;
 #pragma unroll
         for (int ct = 0; ct < G::TPW; ct++) {
-            const int cell = 16 * (G::TPW * CHF + ct) + r;
+            const int cv = TILE_CELL[G::TPW * CHF + ct][r];
+            cellv[ct] = cv;
             int m = 0;
-            if (cell < G::NC) {
+            if (!(cv & 0x100)) {
                 int bl, x, y;
-                cell_xy(cell, bl, x, y);
+                cell_xy(cv, bl, x, y);
                 for (int tap = 0; tap < 9; tap++) {
                     const int xx = x + tap / 3 - 1, yy = y + tap % 3 - 1;
                     if (xx >= 0 && xx < 7 && yy >= 0 && yy < 7)
@@ -845,10 +875,13 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
     const int oh = wave >> 1, kg = lane >> 4;
     afrag aring[RING2][4];
 #pragma unroll
-    for (int i = 0; i < RING2; i++)
+    for (int i = 0; i < RING2; i++) {
+        // walk position i of the first layer (KS_IN = 1: position = inner tap of row 0)
+        const int step = CHF == 0 ? i : 3 * i;
 #pragma unroll
         for (int t = 0; t < 4; t++)
-            aring[i][t] = wp[((size_t)i * 8 + 4 * oh + t) * 64 + lane];
+            aring[i][t] = wp[((size_t)step * 8 + 4 * oh + t) * 64 + lane];
+    }
     f32x16 sh;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -858,17 +891,19 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
             sh[4 * t + i] = t4[i];
     }
     if constexpr (STAMP) st[1] = stamp_now();
-    conv_layer2<DT, G::KS_IN, CHF, STAMP>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
+    conv_layer2<DT, G::KS_IN, CHF, STAMP>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
     __syncthreads();
     if constexpr (STAMP) st[7] = stamp_now();
     wp += l0;
     for (int b = 0; b < A.blocks; b++) {
         const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, wave, lane, st + 8 + 8 * b);
+        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, cellv, wave, lane,
+                                                st + 8 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
         wp += lf;
-        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, wave, lane, st + 12 + 8 * b);
+        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, cellv, wave, lane,
+                                                st + 12 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
         wp += lf;

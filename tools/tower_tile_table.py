@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Generates TILE_CELL of csrc/net_kernels.hip: four 16-cell edge tiles + six residue-class tiles with distinct slots mod 16."""
+import itertools, json
+cells=[(bl,x,y) for y in range(7) for bl in range(3) for x in range(7)]
+cidx={cl:21*cl[2]+7*cl[0]+cl[1] for cl in cells}
+res={cl:cidx[cl]%16 for cl in cells}
+def pick(pred, used, prefer):
+    cand=[cl for cl in cells if pred(cl) and cl not in used]
+    cand.sort(key=prefer)
+    byres={}
+    for cl in cand:
+        byres.setdefault(res[cl],cl)
+    return list(byres.values())
+best=None
+# try different orders / preferences: which tile claims corners first
+preds={'top':lambda c:c[2]==0,'bot':lambda c:c[2]==6,'left':lambda c:c[1]==0,'right':lambda c:c[1]==6}
+for order in itertools.permutations(['top','bot','left','right']):
+    used=set(); tiles={}
+    ok=True
+    for name in order:
+        t=pick(preds[name], used, lambda cl:(cl[1] in(0,6))+(cl[2] in(0,6)))  # prefer non-corners
+        tiles[name]=t; used|=set(t)
+    rest=[cl for cl in cells if cl not in used]
+    cnt=[0]*16
+    for cl in rest: cnt[res[cl]]+=1
+    score=sum(len(t) for t in tiles.values())
+    feas=max(cnt)<=6
+    print(order,[len(tiles[n]) for n in ['top','bot','left','right']],len(rest),max(cnt),feas)
+    if feas and (best is None or score>best[0]): best=(score,order,tiles,rest)
+print(best[0], best[1])
+
+score, order, tiles, rest = best
+# rest tiles: k-th cell of each residue -> rest tile k
+rt=[[None]*16 for _ in range(6)]
+byres={}
+for cl in sorted(rest, key=lambda cl: cidx[cl]):
+    byres.setdefault(res[cl],[]).append(cl)
+for r,lst in byres.items():
+    assert len(lst)<=6
+    for k,cl in enumerate(lst): rt[k][r]=cl
+def lane_tile(t):
+    out=[None]*16
+    for cl in t:
+        assert out[res[cl]] is None
+        out[res[cl]]=cl
+    return out
+T=[lane_tile(tiles['top']), lane_tile(tiles['bot']), rt[0], rt[1], rt[2],
+   lane_tile(tiles['left']), lane_tile(tiles['right']), rt[3], rt[4], rt[5]]
+seen=set()
+rows=[]
+for t in T:
+    row=[]
+    for r,cl in enumerate(t):
+        if cl is None: row.append(0x100|r)
+        else:
+            assert cidx[cl]%16==r and cl not in seen; seen.add(cl); row.append(cidx[cl])
+    rows.append(row)
+assert len(seen)==147
+# checks: skip properties
+for r,cl in enumerate(T[0]): assert cl is None or cl[2]==0
+for r,cl in enumerate(T[1]): assert cl is None or cl[2]==6
+for r,cl in enumerate(T[5]): assert cl is None or cl[1]==0
+for r,cl in enumerate(T[6]): assert cl is None or cl[1]==6
+print("static constexpr unsigned short TILE_CELL[10][16] = {")
+for row in rows:
+    print("    {" + ", ".join("0x%03x" % v for v in row) + "},")
+print("};")
+print([sum(1 for v in row if v<0x100) for row in rows])
