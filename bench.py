@@ -226,9 +226,9 @@ def main():
                        "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},
             "nn_evals_per_s": evals_total / t_max, "plies_per_s": plies_total / t_max,
-            # finished games per second in steady state = plies/s / mean game length; 140.74 plies is the mean
-            # over 11,160 games written by the real CLI in a 180 s soak of this workload
-            "games_per_s": (plies_total / t_max) / 140.74,
+            # finished games per second in steady state = plies/s / mean game length; 147.75 plies is the mean
+            # over 29,296 games written by the real CLI in a 420 s soak of this workload
+            "games_per_s": (plies_total / t_max) / 147.75,
             "games_finished_in_timed_region": games_total,
             "roofline": {"bound": "mfma", "kernel": "%s<%s>" % ("k_tower" if args.dtype == "f32" or os.environ.get("AZH_TOWER") == "1" else "k_tower2", args.dtype), "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
