@@ -222,3 +222,54 @@ def test_parked_descents_match_oracle_and_leave_every_game_unchanged():
         if len(lines0) >= want + 16:
             break
     assert set(g_lines) <= set(lines0)
+
+
+def test_full_size_workload_invariants():
+    """BASELINE's full size (4096 games, 400 sims/move, 12x128 bf16, level budget 48) is checked through
+    size-independent properties of the search: tree bookkeeping identities on sampled games, counter identities over
+    the whole batch, and replay of every game written."""
+    conv, bn = model.random_init(12, 128, seed=1)
+    net = link.Net(conv, bn)
+    G, V = 4096, 400
+    ocfg = orc.make_config(G, V, seed=20260101, select_budget=48)
+    ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+    ge.set_visits(16)
+    lines = []
+    for _ in range(6):
+        ge.run(net, 250, link.DTYPE_BF16)
+        lines += ge.drain_json()
+    ge.set_visits(V)
+    for _ in range(4):
+        ge.run(net, 250, link.DTYPE_BF16)
+        lines += ge.drain_json()
+    ge.sync()
+    st = ge.stats()
+    assert st["edge_overflow"] == 0 and st["ring_overflow"] == 0
+    assert st["games"] == len(lines) > 1000
+    # every step is one descent that ends in an evaluation or a terminal re-hit; evaluations = steps that reached a new
+    # non-terminal node + one root (re-)evaluation per ply and per game start
+    assert st["steps"] <= 2500 * G and st["nn_evals"] <= st["steps"] + st["plies"] + st["games"] + st["dropped"] + G
+    assert st["levels"] >= st["steps"]  # every descent looks at the root at least
+    rng = np.random.default_rng(0)
+    for g in rng.choice(G, size=48, replace=False):
+        s = ge.game_state(int(g))
+        boards, info, edges, moves = ge.tree(int(g))
+        assert 1 <= s.n_nodes <= ge.node_cap and s.n_edges <= ge.edge_cap
+        first, m = int(info[0, 0]), int(info[0, 1] & 0xFFFF)
+        assert int(edges[first:first + m, 1].sum()) == s.root_visits
+        kids = edges[:, 3][edges[:, 3] != 0xFFFFFFFF]
+        assert len(set(kids.tolist())) == len(kids) == s.n_nodes - 1  # a tree: every node but the root has one parent
+        n = edges[:, 1].astype(np.float64)
+        w = edges[:, 2].copy().view(np.float32).astype(np.float64)
+        assert ((w >= -1e-6) & (w <= n + 1e-3)).all()  # W / n is a probability of winning
+        # visits of an edge = 1 (the expansion) + visits below it, for every expanded non-terminal child
+        # (a parked descent has not backed up yet, so the identity is exact at every sync point)
+        for e_idx in np.nonzero(edges[:, 3] != 0xFFFFFFFF)[0][:64]:
+            c = int(edges[e_idx, 3])
+            cf, cm, cres = int(info[c, 0]), int(info[c, 1] & 0xFFFF), int(info[c, 1] >> 16)
+            if cres == 0 and cm > 0:
+                assert int(edges[e_idx, 1]) == 1 + int(edges[cf:cf + cm, 1].sum()), (int(g), int(e_idx))
+    for line in lines[:: max(1, len(lines) // 200)]:
+        entry = json.loads(line)
+        assert entry["result"] in (1, 2)
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]

@@ -85,3 +85,27 @@ def test_symmetry_averaged_forward_matches_nn_evals_restatement():
         assert np.abs(p16 - p).max() < 5e-2 and np.abs(v16 - v).max() < 5e-2
     p0, v0 = net.forward_sym(lb[:0], 0, link.DTYPE_F32)
     assert p0.shape == (0, 7, 7, 17)
+
+
+@pytest.mark.parametrize("dtype", [link.DTYPE_BF16, link.DTYPE_F16, link.DTYPE_F32])
+def test_full_size_launch_is_position_independent(dtype):
+    """A 16384-board launch (the bench's largest): a board's logits and value do not depend on which workgroup
+    computes it or on its neighbours — bit for bit at equal board slot (index mod 3).  The f32 tower is bit-identical in
+    every slot; the 16-bit tower sums the taps of the two wave halves in different orders (compile-time tap skipping),
+    so across slots it agrees to rounding only."""
+    conv, bn = model.random_init(12, 128, seed=1)
+    net = link.Net(conv, bn)
+    base = sample_leaf_boards(1021, 9, BLOCK4_MASK)          # 1021 is prime: every board meets every slot of a workgroup
+    big = np.concatenate([base] * 17)[:16384]
+    p, v = net.forward(big, BLOCK4_MASK, dtype)
+    assert np.isfinite(p).all() and np.isfinite(v).all() and (np.abs(v) <= 1).all()
+    tol = {link.DTYPE_BF16: 3e-2, link.DTYPE_F16: 6e-3, link.DTYPE_F32: 0.0}[dtype]
+    for rep in range(1, 16):
+        lo = rep * 1021
+        n = min(1021, 16384 - lo)
+        if lo % 3 == 0 or dtype == link.DTYPE_F32:
+            assert (p[lo:lo + n] == p[:n]).all() and (v[lo:lo + n] == v[:n]).all()
+        else:
+            assert np.abs(p[lo:lo + n] - p[:n]).max() <= tol and np.abs(v[lo:lo + n] - v[:n]).max() <= tol
+    small_p, small_v = net.forward(base[:37], BLOCK4_MASK, dtype)
+    assert (small_p == p[:37]).all() and (small_v == v[:37]).all()
