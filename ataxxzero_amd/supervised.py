@@ -16,44 +16,53 @@ MAXIMUM_GAME_PLIES = 400
 OPENING_RANDOMIZATION_SCHEDULE = [0.2 * (0.5 ** (i / 2)) for i in range(10)]  # generate_games.py:11-14
 
 
-class UAIPlayer:
-    """The master side of the UAI dialogue (uai_ringmaster.py:9-60)."""
+class Teacher:
+    """The master side of a UAI dialogue with an engine subprocess (what uai_ringmaster.py:9-60 does for the
+    reference): handshake on start, `position fen` + `go movetime` per move, `quit` on exit."""
 
-    def __init__(self, cmd):
-        self.cmd = cmd
-        self.proc = subprocess.Popen(cmd, shell=isinstance(cmd, str), stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                     stderr=subprocess.DEVNULL)
-        self.send("uai\n")
-        self.send("setoption name Hash value 1024\n")
-        self.send("isready\n")
-        self.send("uainewgame\n")
+    HANDSHAKE = ("uai", "setoption name Hash value 1024", "isready", "uainewgame")
 
-    def send(self, s):
-        self.proc.stdin.write(s.encode("utf8"))
-        self.proc.stdin.flush()
+    def __init__(self, command):
+        self.command = command
+        self.process = subprocess.Popen(command, shell=isinstance(command, str), stdin=subprocess.PIPE,
+                                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        self.tell(*self.HANDSHAKE)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.quit()
+
+    def tell(self, *lines):
+        self.process.stdin.write(("\n".join(lines) + "\n").encode("utf8"))
+        self.process.stdin.flush()
 
     def quit(self):
         try:
-            self.send("quit\n")
+            self.tell("quit")
         except (BrokenPipeError, OSError):
             pass
         try:
-            self.proc.wait(timeout=5)
+            self.process.wait(timeout=5)
         except subprocess.TimeoutExpired:
-            self.proc.kill()
-            self.proc.wait()
+            self.process.kill()
+            self.process.wait()
 
     def set_state(self, position):
-        self.send("position fen %s\n" % position.fen())
+        self.tell("position fen " + position.fen())
 
     def genmove(self, ms=1000):
-        self.send("go movetime %i\n" % ms)
-        while True:
-            line = self.proc.stdout.readline().strip().decode("utf8")
-            if not line:
-                raise Exception("Bad UAI!")
-            if line.startswith("bestmove "):
-                return uai.decode_move(line[9:].split()[0])
+        """-> u16 move; raises when the engine closes its output without a bestmove."""
+        self.tell("go movetime %i" % ms)
+        for raw in iter(self.process.stdout.readline, b""):
+            words = raw.decode("utf8").split()
+            if words and words[0] == "bestmove":
+                return uai.decode_move(words[1])
+        raise Exception("Bad UAI!")
+
+
+UAIPlayer = Teacher  # the reference's name for it
 
 
 def generate_game(teacher, ms, rng=random):

@@ -32,102 +32,96 @@ DELTA_LAYER = {d: i for i, d in enumerate(FAR_OFFSETS)}
 
 # ---------------------------------------------------------------- sample pipeline (train.py:11-89)
 
-def uai_decode_square(s):
-    return "abcdefg".index(s[0].lower()), 6 - (int(s[1]) - 1)          # uai_interface.py:19-22
-
-
-def uai_decode_move(s):
-    if s in ("pass", "none", "0000"):
-        return "pass"
-    if len(s) == 2:
-        return "c", uai_decode_square(s)
-    return uai_decode_square(s[:2]), uai_decode_square(s[2:])          # uai_interface.py:24-32
+def uai_decode_move(text):
+    """UAI text -> the reference's move value ("pass" | ("c", (x, y)) | ((x0, y0), (x1, y1)))."""
+    from .uai import text_to_xy_move
+    return text_to_xy_move(text)
 
 
 def board_to_features(cells, to_move):
-    """engine.py:53-73 with BLOCKED_CELLS = frozenset(): planes ones / mover / opponent / blockers."""
-    f = np.zeros((BOARD, BOARD, 4), dtype=np.int8)
-    f[:, :, 0] = 1
-    for y in range(BOARD):
-        for x in range(BOARD):
-            piece = cells[x + y * BOARD]
-            if piece == to_move:
-                f[x, y, 1] = 1
-            elif piece != 0:
-                f[x, y, 2] = 1
-    return f
+    """Four planes [x][y][c] — ones, mover's stones, opponent's stones, blockers (none in training files) — from the 49
+    recorded cells (index x + 7 y), engine.py:53-73."""
+    grid = np.asarray(cells, dtype=np.int8).reshape(BOARD, BOARD).T      # grid[x, y]
+    planes = np.zeros((BOARD, BOARD, 4), dtype=np.int8)
+    planes[..., 0] = 1
+    planes[..., 1] = grid == to_move
+    planes[..., 2] = (grid != 0) & (grid != to_move)
+    return planes
+
+
+def _symmetry_bits(index):
+    if not 0 <= index < 8:
+        raise ValueError("symmetry index %r" % (index,))
+    return bool(index & 1), bool(index & 2), bool(index & 4)
 
 
 def apply_symmetry(index, arr):
-    coin1, coin2, coin3 = index & 1, (index >> 1) & 1, (index >> 2) & 1   # train.py:11-23
-    arr = np.array(arr).copy()
-    if coin1:
-        arr = arr[::-1, :, :].copy()
-    if coin2:
-        arr = arr[:, ::-1, :].copy()
-    if coin3:
-        arr = np.swapaxes(arr.copy(), 0, 1).copy()
-    return arr
+    """The dihedral symmetry `index` of train.py:11-23 on an [x][y][c] array: bit 0 mirrors x, bit 1 mirrors y,
+    bit 2 then transposes; always a fresh array."""
+    flip_x, flip_y, transpose = _symmetry_bits(index)
+    out = np.array(arr)
+    if flip_x:
+        out = np.flip(out, axis=0)
+    if flip_y:
+        out = np.flip(out, axis=1)
+    if transpose:
+        out = np.transpose(out, (1, 0, 2))
+    return np.ascontiguousarray(out)
 
 
 def apply_symmetry_to_move(index, move):
-    coin1, coin2, coin3 = index & 1, (index >> 1) & 1, (index >> 2) & 1   # train.py:25-40
+    """The same symmetry on a move value (train.py:25-40)."""
+    flip_x, flip_y, transpose = _symmetry_bits(index)
+    last = BOARD - 1
 
-    def coord(xy):
-        x, y = xy
-        if coin1:
-            x = (BOARD - 1) - x
-        if coin2:
-            y = (BOARD - 1) - y
-        if coin3:
-            x, y = y, x
-        return x, y
+    def image(xy):
+        x = last - xy[0] if flip_x else xy[0]
+        y = last - xy[1] if flip_y else xy[1]
+        return (y, x) if transpose else (x, y)
 
-    start, end = move
-    if start == "c":
-        return "c", coord(end)
-    return coord(start), coord(end)
+    return tuple(part if part == "c" else image(part) for part in move)
 
 
 def add_move_to_heatmap(heatmap, move, coef=1):
-    start, end = move                                                     # engine.py:79-87
-    if start == "c":
-        heatmap[end[0], end[1], MOVE_TYPES - 1] += coef
+    """Policy plane of a move: clones in the last layer of the destination cell, jumps in the layer of their
+    (dx, dy) (engine.py:75-87)."""
+    source, (tx, ty) = move
+    layer = MOVE_TYPES - 1 if source == "c" else DELTA_LAYER[(tx - source[0], ty - source[1])]
+    heatmap[tx, ty, layer] += coef
+
+
+def _policy_target(entry, ply, symmetry_index):
+    target = np.zeros((BOARD, BOARD, MOVE_TYPES), dtype=np.float32)
+    if "dists" in entry:
+        weighted = entry["dists"][ply].items()
     else:
-        heatmap[end[0], end[1], DELTA_LAYER[(end[0] - start[0], end[1] - start[1])]] += coef
-
-
-def uai_encode_square(xy):
-    return "%s%i" % ("abcdefg"[xy[0]], (6 - xy[1]) + 1)
+        weighted = [(entry["moves"][ply], 1)]       # one-hot on the move played (random / teacher games)
+    for mv, weight in weighted:
+        if isinstance(mv, str):
+            mv = uai_decode_move(mv)
+        else:                                       # json turned the tuples into lists
+            mv = (mv[0] if mv[0] == "c" else tuple(mv[0]), tuple(mv[1]))
+        add_move_to_heatmap(target, apply_symmetry_to_move(symmetry_index, mv), weight)
+    if abs(1 - target.sum()) >= 1e-3:
+        raise AssertionError("policy target does not sum to one")
+    return target
 
 
 def get_sample_from_entries(entries):
-    while True:                                                           # train.py:43-77
+    """One training sample (train.py:43-77).  The draws from `random` come in the reference's order — game, ply,
+    symmetry — so a games file yields the same minibatches as there."""
+    while True:
         entry = random.choice(entries)
         ply = random.randrange(len(entry["boards"]))
-        if "random_ply" in entry:
+        if "random_ply" in entry:                   # ONE_RANDOM_MOVE games: the position right after the random move
             ply = entry["random_ply"] + 1
-        to_move = 1 if ply % 2 == 0 else 2
-        move = entry["moves"][ply]
-        if move == "pass":
+        if entry["moves"][ply] == "pass":
             continue
-        features = board_to_features(entry["boards"][ply], to_move)
-        desired_value = [1 if entry["result"] == to_move else -1]
+        mover = 1 + ply % 2                         # x (1) moves on even plies
         symmetry_index = random.randrange(8)
-        features = apply_symmetry(symmetry_index, features)
-        desired_policy = np.zeros((BOARD, BOARD, MOVE_TYPES), dtype=np.float32)
-        if "dists" not in entry:
-            moves = [(move, 1)]
-        else:
-            moves = list(entry["dists"][ply].items())
-        for mv, probability in moves:
-            if isinstance(mv, str):
-                mv = uai_decode_move(mv)
-            else:
-                mv = (mv[0] if mv[0] == "c" else tuple(mv[0]), tuple(mv[1]))
-            add_move_to_heatmap(desired_policy, apply_symmetry_to_move(symmetry_index, mv), probability)
-        assert abs(1 - desired_policy.sum()) < 1e-3
-        return features, desired_policy, desired_value
+        features = apply_symmetry(symmetry_index, board_to_features(entry["boards"][ply], mover))
+        value = [1 if entry["result"] == mover else -1]
+        return features, _policy_target(entry, ply, symmetry_index), value
 
 
 def load_entries(paths):

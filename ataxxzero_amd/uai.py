@@ -152,3 +152,94 @@ class Searcher:
                 return mv
             x -= w * norm
         return next(iter(weights))
+
+
+# ---------------------------------------------------------------- text protocol
+
+def xy_to_square(xy):
+    """(x, y) with y = 0 at rank 7 (the reference's board coordinates) -> "a7"-style square."""
+    return FILES[xy[0]] + str(7 - xy[1])
+
+
+def square_to_xy(text):
+    return FILES.index(text[0].lower()), 7 - int(text[1])
+
+
+def xy_move_to_text(move):
+    """Reference move value ("pass" | ("c", (x, y)) | ((x0, y0), (x1, y1))) -> UAI text."""
+    if move == "pass":
+        return "0000"
+    return "".join(xy_to_square(part) for part in move if part != "c")
+
+
+def text_to_xy_move(text):
+    if text in ("pass", "none", "0000"):
+        return "pass"
+    if len(text) not in (2, 4):
+        raise Exception("Bad UAI move string: %r" % (text,))
+    squares = [square_to_xy(text[k:k + 2]) for k in range(0, len(text), 2)]
+    return ("c", squares[0]) if len(squares) == 1 else (squares[0], squares[1])
+
+
+class Session:
+    """One UAI dialogue (the command set of uai_interface.py:41-88) over a Searcher.  Commands are looked up in a
+    table of (prefix, handler) pairs; every handler returns the lines to print."""
+
+    def __init__(self, searcher, visits=None, safety_ms=0, show_game=False, log=None):
+        self.searcher, self.visits, self.safety_ms, self.show_game, self.log = searcher, visits, safety_ms, show_game, log
+        self.position = Position.initial()
+        self.table = [
+            ("uainewgame", self.on_newgame),
+            ("uai", self.on_hello),
+            ("isready", lambda rest: ["readyok"]),
+            ("moves ", self.on_moves),
+            ("position fen ", self.on_fen),
+            ("go movetime ", self.on_go),
+            ("showboard", lambda rest: str(self.position).split("\n") + ["boardok"]),
+        ]
+
+    def on_hello(self, rest):
+        return ["id name AtaxxZero-MI355X", "id author ataxxzero_amd", "uaiok"]
+
+    def on_newgame(self, rest):
+        self.position = Position.initial()
+        return []
+
+    def on_moves(self, rest):
+        for text in rest.split():
+            self.position.move(decode_move(text))
+        return []
+
+    def on_fen(self, rest):
+        self.position = Position.from_fen(rest)
+        if self.show_game and self.log is not None:
+            print("===\n%s" % (self.position,), file=self.log)
+        return []
+
+    def on_go(self, rest):
+        if self.visits is not None:
+            move = self.searcher.genmove(self.position, visits=self.visits)
+        else:
+            budget_ms = max(int(rest) - self.safety_ms, 1)
+            move = self.searcher.genmove(self.position, seconds=budget_ms * 1e-3)
+        speed = self.searcher.last_steps / self.searcher.last_seconds
+        return ["info speed %f nps" % (speed,), "bestmove %s" % (encode_move(move),)]
+
+    def handle(self, line):
+        """-> (lines to print, keep going)."""
+        if line == "quit":
+            return [], False
+        for prefix, handler in self.table:
+            exact = not prefix.endswith(" ")
+            if (line == prefix) if exact else line.startswith(prefix):
+                return handler(line[len(prefix):]), True
+        return [], True  # unknown commands are ignored, as the reference does
+
+    def serve(self, source, sink):
+        for raw in source:
+            out, more = self.handle(raw.rstrip("\n"))
+            for text in out:
+                print(text, file=sink)
+            sink.flush()
+            if not more:
+                break

@@ -1,97 +1,39 @@
 #!/usr/bin/python
-"""Drop-in for the reference's uai_interface.py: the UAI text-protocol engine (uai_interface.py:41-88)
-over the GPU search, so the net can play any UAI master — including the reference's unmodified
-uai_ringmaster.py — as `python uai_interface.py --network-path X.npy [--visits N]`.
+"""UAI engine over the GPU search: `python uai_interface.py --network-path X.npy [--visits N]`.
 
-Also exports the reference's move/square codecs (uai_interface.py:6-32) under the same names.
+Stands in for the reference's script of the same name (command set uai_interface.py:41-88, options :97-100), so
+any UAI master — the reference's unmodified uai_ringmaster.py included — can drive the net.  The dialogue itself
+lives in ataxxzero_amd/uai.py (Session); the four codec helpers other reference modules import from here
+(train.py:64-69, uai_ringmaster.py:42,59) are re-exported under their reference names.
 """
-import string
+import argparse
 import sys
 
+from ataxxzero_amd.uai import square_to_xy as uai_decode_square
+from ataxxzero_amd.uai import text_to_xy_move as uai_decode_move
+from ataxxzero_amd.uai import xy_move_to_text as uai_encode_move
+from ataxxzero_amd.uai import xy_to_square as uai_encode_square
 
-def uai_encode_square(xy):
-    x, y = xy
-    y = 6 - y
-    return "%s%i" % (string.ascii_lowercase[x], y + 1)
-
-
-def uai_encode_move(move):
-    if move == "pass":
-        return "0000"
-    start, end = move
-    if start == "c":
-        return uai_encode_square(end)
-    return "%s%s" % (uai_encode_square(start), uai_encode_square(end))
+__all__ = ["uai_encode_square", "uai_encode_move", "uai_decode_square", "uai_decode_move", "main"]
 
 
-def uai_decode_square(s):
-    x, y = string.ascii_lowercase.index(s[0].lower()), int(s[1]) - 1
-    y = 6 - y
-    return x, y
-
-
-def uai_decode_move(s):
-    if s in ("pass", "none", "0000"):
-        return "pass"
-    elif len(s) == 2:
-        return "c", uai_decode_square(s)
-    elif len(s) == 4:
-        return uai_decode_square(s[:2]), uai_decode_square(s[2:])
-    else:
-        raise Exception("Bad UAI move string: %r" % s)
-
-
-def main(args):
+def main(options):
     from ataxxzero_amd import selfplay, uai
     selfplay.select_device(0)
-    searcher = uai.Searcher(args.network_path, dtype=args.dtype, symmetry_average=args.symmetry_average)
-    board = uai.Position.initial()
-    while True:
-        try:
-            line = input()
-        except EOFError:
-            return
-        if line == "quit":
-            return
-        elif line == "uai":
-            print("id name AtaxxZero-MI355X")
-            print("id author ataxxzero_amd")
-            print("uaiok")
-        elif line == "uainewgame":
-            board = uai.Position.initial()
-        elif line == "isready":
-            print("readyok")
-        elif line.startswith("moves "):
-            for move in line[6:].split():
-                board.move(uai.decode_move(move))
-        elif line.startswith("position fen "):
-            board = uai.Position.from_fen(line[13:])
-            if args.show_game:
-                print("===", file=sys.stderr)
-                print(board, file=sys.stderr)
-        elif line.startswith("go movetime "):
-            ms = int(line[12:]) - args.safety_ms
-            if args.visits is None:
-                move = searcher.genmove(board, seconds=max(ms, 1) * 1e-3)
-            else:
-                move = searcher.genmove(board, visits=args.visits)
-            print("info speed %f nps" % (searcher.last_steps / searcher.last_seconds,))
-            print("bestmove %s" % (uai.encode_move(move),))
-        elif line == "showboard":
-            print(board)
-            print("boardok")
-        sys.stdout.flush()
+    searcher = uai.Searcher(options.network_path, dtype=options.dtype, symmetry_average=options.symmetry_average)
+    session = uai.Session(searcher, visits=options.visits, safety_ms=options.safety_ms, show_game=options.show_game,
+                          log=sys.stderr)
+    session.serve(sys.stdin, sys.stdout)
 
 
 if __name__ == "__main__":
-    import argparse
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--network-path", metavar="NETWORK", type=str, help="Name of the model to load.")
-    parser.add_argument("--visits", metavar="VISITS", default=None, type=int, help="Number of visits during MCTS.")
-    parser.add_argument("--safety-ms", metavar="MS", default=0, type=int, help="Number of milliseconds to shave off of each movetime for safety.")
-    parser.add_argument("--show-game", action="store_true", help="Show the game on stderr.")
-    parser.add_argument("--symmetry-average", action="store_true", help="Evaluate every position as the mean over its 8 dihedral images (nn_evals.py:48-62; extension).")
-    parser.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="Tower arithmetic (extension).")
-    args = parser.parse_args()
-    print(args, file=sys.stderr)
-    main(args)
+    cli = argparse.ArgumentParser(description="UAI engine: MCTS and the policy/value net on one MI355X.")
+    cli.add_argument("--network-path", required=True, metavar="NPY", help=".npy weight file in the model.py layout")
+    cli.add_argument("--visits", type=int, default=None, metavar="N", help="search exactly N steps per move instead of using the clock")
+    cli.add_argument("--safety-ms", type=int, default=0, metavar="MS", help="margin subtracted from every movetime")
+    cli.add_argument("--show-game", action="store_true", help="echo positions set by `position fen` to stderr")
+    cli.add_argument("--symmetry-average", action="store_true", help="evaluate every position as the mean over its 8 dihedral images (nn_evals.py:48-62; extension)")
+    cli.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="tower arithmetic (extension)")
+    options = cli.parse_args()
+    print(options, file=sys.stderr)
+    main(options)

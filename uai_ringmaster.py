@@ -18,6 +18,7 @@ import shlex
 import sys
 
 from ataxxzero_amd import arena, model, selfplay
+from ataxxzero_amd.cli import flag, parse, switch
 
 
 def parse_engine(cmd):
@@ -32,19 +33,22 @@ def parse_engine(cmd):
 
 
 if __name__ == "__main__":
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--engine", metavar="CMD", action="append", help="Engine command.")
-    parser.add_argument("--show-games", action="store_true", help="(reference flag; not supported by the batched arena)")
-    parser.add_argument("--opening", metavar="MOVES", type=str, default=None, help="(reference flag; only the empty opening is supported)")
-    parser.add_argument("--max-plies", metavar="N", type=int, default=None, help="Maximum number of plies in a game before it's aborted and rejected.")
-    parser.add_argument("--pgn-out", metavar="PATH", type=str, default=None, help="PGN file path to accumulate games into. Writes in append mode.")
-    parser.add_argument("--gauntlet", action="store_true", help="Just the first engine plays against all the other engines.")
-    parser.add_argument("--tc", metavar="SEC", type=float, default=1.0, help="Seconds per move (recorded in the PGN; search is visit-limited).")
-    parser.add_argument("--game-count", metavar="N", type=int, default=1000, help="Stop after N games (extension: the reference loops forever).")
-    parser.add_argument("--concurrent", metavar="N", type=int, default=None, help="Games in flight on the GPU (extension).")
-    parser.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="Tower arithmetic (extension).")
-    parser.add_argument("--seed", type=int, default=selfplay.DEFAULT_SEED, help="Philox seed (extension).")
-    args = parser.parse_args()
+    args = parse("Head-to-head match of two networks, both searched on one MI355X.", [
+        flag("--engine", "engine command line (twice): python uai_interface.py --network-path X.npy --visits N",
+             metavar="CMD", action="append"),
+        switch("--show-games", "reference flag, not provided by the batched arena"),
+        flag("--opening", "reference flag; only the empty opening is provided", metavar="MOVES"),
+        flag("--max-plies", "games longer than this are cut and annulled", type=int, metavar="N"),
+        flag("--pgn-out", "PGN file the games are appended to", metavar="PGN"),
+        switch("--gauntlet", "first engine against all others (with two engines: the same match)"),
+        flag("--tc", "seconds per move, recorded in the PGN (the search is visit-limited)", type=float, default=1.0,
+             metavar="SEC"),
+        flag("--game-count", "stop after this many games (extension: the reference never stops)", type=int, default=1000,
+             metavar="N"),
+        flag("--concurrent", "games in flight on the GPU (extension)", type=int, metavar="N"),
+        flag("--dtype", "tower arithmetic (extension)", default="bf16", choices=["bf16", "f16", "f32"]),
+        flag("--seed", "Philox seed (extension)", type=int, default=selfplay.DEFAULT_SEED),
+    ])
     print("Options:", args)
     if not args.engine or len(args.engine) != 2:
         raise SystemExit("uai_ringmaster.py: the GPU arena plays exactly two --engine commands against each other")
