@@ -71,17 +71,15 @@ def forward(conv_weights, bn_params, features, dtype=np.float64):
 
 
 def apply_symmetry(tensor, symmetry):
-    """nn_evals.py:8-16 on a (7,7,k) tensor."""
-    if symmetry & 1:
-        tensor = tensor[::-1, :]
-    if symmetry & 2:
-        tensor = tensor[:, ::-1]
-    if symmetry & 4:
-        tensor = np.moveaxis(tensor, 0, 1)
-    return tensor
+    """The dihedral image `symmetry` (0..7) of a (7,7,k) tensor as nn_evals.py:8-16 defines it: bit 0 mirrors the first
+    axis, bit 1 the second, bit 2 then swaps the two."""
+    axes = [axis for axis, bit in ((0, 1), (1, 2)) if symmetry & bit]
+    image = np.flip(tensor, axis=axes) if axes else tensor
+    return np.swapaxes(image, 0, 1) if symmetry & 4 else image
 
 
-INVERSE_SYMMETRY = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 6, 6: 5, 7: 7}   # nn_evals.py:27
+# inverse of every image under composition (nn_evals.py:27): the two mirror-then-swap images 5 and 6 undo each other
+INVERSE_SYMMETRY = {s: (s if s not in (5, 6) else 11 - s) for s in range(8)}
 
 
 def forward_sym(conv_weights, bn_params, features, dtype=np.float64):
