@@ -893,9 +893,8 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     }
 }
 
-// The three tree phases as kernels (step-wise API) and fused (device-resident loop): one wave
-// owns a game through backup -> advance -> select, so a slow re-root only delays its own game
-// and a step costs one launch instead of three.
+// The tree phases as kernels (step-wise API) and fused (device-resident loop): one wave owns a game through
+// backup -> mark -> select, so a step costs one launch instead of three.
 __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
 {
     __shared__ TreeLds L;
@@ -1264,8 +1263,9 @@ static int enqueue_compact(azh_engine *e)
     return 0;
 }
 
-// Device-resident loop.  Iteration = select -> tower -> backup -> advance; consecutive iterations
-// run backup+advance+select of one game in a single fused launch.
+// Device-resident loop.  Iteration = select -> tower -> backup -> "is the move due?"; consecutive iterations run
+// backup + mark + the next select of one game in a single fused launch (k_tree), and the queued re-roots
+// (k_advance_list) on the side stream under the next tower.
 static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations)
 {
     if (iterations <= 0)

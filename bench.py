@@ -234,7 +234,8 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": tm["net_ms"] / it, "evals_per_launch": d["nn_evals"] / float(args.steps * args.streams),
                          "flops_per_eval": flops},
-            "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup+advance+select, fused) + k_compact",
+            "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup + move-due mark + select, fused) + k_compact on the engine's stream; "
+                                         "k_advance_list (re-roots) runs on a side stream under the tower",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS,
                               "select_ms_per_step": tm["select_ms"] / it, "backup_ms_per_step": tm["backup_ms"] / it,
                               "bytes_per_step": tree_bytes(d) / float(max(d["steps"], 1)),
