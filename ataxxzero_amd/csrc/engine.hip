@@ -1002,6 +1002,7 @@ struct azh_engine {
     bool timing = false;
     std::vector<hipEvent_t> events;  // 4 per recorded iteration
     size_t ev_used = 0;
+    std::vector<char> ev_closed;  // per timed iteration: ev[3] was recorded (last iteration of a run call)
     std::vector<int> ev_evals;
     int *h_count = nullptr;  // pinned
     bool selected = false;
@@ -1297,8 +1298,12 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         AZH_HIP(hipGetLastError());
         if (!last && side_advance()) return -1;
         if (rec) {
-            // ev[1]..ev[2] = tower; ev[2]..ev[3] = the tree phases (+ compaction) that follow it
-            AZH_HIP(hipEventRecord(ev[3], e->stream));
+            // ev[1]..ev[2] = tower; ev[2]..next iteration's ev[1] = the tree phases (+ compaction) that follow it.
+            // Only the last iteration of a call closes its tree phase with an event of its own: every event is a
+            // barrier packet in the queue (~4 us), and three per iteration showed up as idle gaps in the kernel trace.
+            e->ev_closed[e->ev_used / 4] = last != 0;
+            if (last)
+                AZH_HIP(hipEventRecord(ev[3], e->stream));
             e->ev_used += 4;
         }
     }
@@ -1390,6 +1395,7 @@ extern "C" int azh_engine_timing_reset(azh_engine *e, int enable)
         e->events.resize(4 * MAX_TIMED_ITERS);
         for (auto &ev : e->events)
             AZH_HIP(hipEventCreate(&ev));
+        e->ev_closed.assign(MAX_TIMED_ITERS, 0);
     }
     return 0;
 }
@@ -1403,9 +1409,13 @@ extern "C" int azh_engine_timing(azh_engine *e, azh_timing *out)
     for (size_t i = 0; i + 4 <= e->ev_used; i += 4) {
         float b = 0, c = 0;
         AZH_HIP(hipEventElapsedTime(&b, e->events[i + 1], e->events[i + 2]));
-        AZH_HIP(hipEventElapsedTime(&c, e->events[i + 2], e->events[i + 3]));
+        // the tree phase ends at its own event (last iteration of a call) or at the next iteration's tower start
+        const bool closed = e->ev_closed[i / 4] != 0;
+        if (!closed && i + 8 > e->ev_used)
+            break;  // cannot happen: the last timed iteration of a call is always closed
+        AZH_HIP(hipEventElapsedTime(&c, e->events[i + 2], closed ? e->events[i + 3] : e->events[i + 5]));
         out->net_ms += b;
-        out->select_ms += c;  // the fused tree launch (backup + advance + select) and the compaction
+        out->select_ms += c;  // the fused tree launch (backup + mark + select) and the compaction
         out->iterations += 1;
     }
     return 0;

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Timeline of one steady-state iteration from rocprofv3's kernel trace of bench.py: durations and the gaps between
+# tower -> k_tree -> k_compact -> next tower (run on the GPU box from the repo root).
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/gap_trace
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 400 --warmup 100 --phase-mix 1500 --phase-fill 400 --no-cpu-baseline --no-target-leg > $OUT/trace.log 2>&1 || exit 1
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, os
+f = max(glob.glob(os.path.join(sys.argv[1], "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]) for r in csv.DictReader(open(f))]
+rows.sort()
+main = [r for r in rows if r[2] in ("k_tower2", "k_tree", "k_compact")]
+tail = main[-3 * 300:]
+import collections
+gaps = collections.defaultdict(list); durs = collections.defaultdict(list)
+for a, b in zip(tail, tail[1:]):
+    durs[a[2]].append(a[1] - a[0])
+    gaps[a[2] + " -> " + b[2]].append(b[0] - a[1])
+for k, v in durs.items():
+    v.sort(); print("duration %-10s p50 %.1f us  mean %.1f us" % (k, v[len(v)//2]/1e3, sum(v)/len(v)/1e3))
+for k, v in gaps.items():
+    v.sort(); print("gap %-24s p50 %.1f us  mean %.1f us" % (k, v[len(v)//2]/1e3, sum(v)/len(v)/1e3))
+adv = [r for r in rows if r[2] == "k_advance_list"][-300:]
+v = sorted(e - s for s, e, _ in adv); print("k_advance_list (side stream) p50 %.1f us  p90 %.1f us  max %.1f us" % (v[len(v)//2]/1e3, v[9*len(v)//10]/1e3, v[-1]/1e3))
+PY
+rm -rf $OUT/trace
