@@ -82,14 +82,20 @@ def apply_symmetry(tensor, symmetry):
 INVERSE_SYMMETRY = {s: (s if s not in (5, 6) else 11 - s) for s in range(8)}
 
 
-def forward_sym(conv_weights, bn_params, features, dtype=np.float64):
-    """nn_evals.evaluate (nn_evals.py:48-62) for a batch: the net on the 8 dihedral images of every
-    board, policies brought back with the inverse symmetry (spatial axes only) and averaged, values
-    averaged.  -> (policy (n,7,7,17), value (n,1))."""
-    features = np.asarray(features, dtype=dtype)
+def sym_average(evaluate, features):
+    """nn_evals.evaluate (nn_evals.py:48-62) for a batch, around any evaluator `evaluate(images (m,7,7,4)) ->
+    (policy (m,7,7,17), value (m,1))`: the evaluator on the 8 dihedral images of every board, policies brought back
+    with the inverse symmetry (spatial axes only) and averaged, values averaged.  Pinned by
+    tests/golden/nn_evals_sym.npz (the reference's own nn_evals.evaluate around the same injected evaluator)."""
     n = len(features)
     images = np.stack([apply_symmetry(f, s) for f in features for s in range(8)])
-    policy, value = forward(conv_weights, bn_params, images, dtype=dtype)
-    policy = policy.reshape(n, 8, 7, 7, 17)
+    policy, value = evaluate(images)
+    policy = np.asarray(policy).reshape(n, 8, 7, 7, 17)
     back = np.stack([np.stack([apply_symmetry(policy[i, s], INVERSE_SYMMETRY[s]) for s in range(8)]) for i in range(n)])
-    return back.mean(axis=1), value.reshape(n, 8).mean(axis=1).reshape(n, 1)
+    return back.mean(axis=1), np.asarray(value).reshape(n, 8).mean(axis=1).reshape(n, 1)
+
+
+def forward_sym(conv_weights, bn_params, features, dtype=np.float64):
+    """sym_average around the restated net.  -> (policy (n,7,7,17), value (n,1))."""
+    features = np.asarray(features, dtype=dtype)
+    return sym_average(lambda images: forward(conv_weights, bn_params, images, dtype=dtype), features)
