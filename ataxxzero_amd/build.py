@@ -29,7 +29,7 @@ UNITS = [
 
 
 def _deps():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cuh"))] + \
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(os.path.dirname(HERE), "include", "ataxxzero_hip.h"), os.path.abspath(__file__)]
 
 
@@ -76,5 +76,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# Bench-only target: the reference's architecture (one host thread per game + batched evaluator) as the CPU
+# baseline bench.py times beside the GPU path.  A separate library on purpose: the product library has no CPU path.
+BASELINE_SRC = os.path.join(os.path.dirname(HERE), "tools", "cpu_baseline", "host_selfplay.hip")
+BASELINE_LIB = os.path.join(os.path.dirname(HERE), "tools", "cpu_baseline", "libazh_cpu_baseline.so")
+
+
+def build_cpu_baseline(force=False):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        if os.path.exists(BASELINE_LIB):
+            return BASELINE_LIB
+        raise RuntimeError("hipcc not found and no prebuilt %s" % BASELINE_LIB)
+    if force or _stale(BASELINE_LIB, [BASELINE_SRC, os.path.join(CSRC, "azh_device.h")]):
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH, "-pthread",
+                               BASELINE_SRC, "-o", BASELINE_LIB])
+    return BASELINE_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_cpu_baseline(force="--force" in sys.argv))

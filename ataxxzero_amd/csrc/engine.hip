@@ -28,8 +28,9 @@
 // engine reproduces oracle/mcts_oracle.c bit for bit (ties -> last maximal edge,
 // Philox-keyed randomness, fixed f32 operation order; compiled -ffp-contract=off).
 #include <algorithm>
+#include <map>
 
-#include "azh_device.cuh"
+#include "azh_device.h"
 #include "azh_host.h"
 
 namespace azh {
@@ -832,7 +833,28 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
 
     u64 st_games = 0, st_dropped = 0, st_ring = 0;
     const bool cut = result == 0 && s.ply >= P.max_plies;
-    if (result != 0 || (cut && (P.flags & AZH_FLAG_KEEP_UNFINISHED))) {
+    // ONE_RANDOM_MOVE: "Skipping game with no board state just after the uniformly random move" (:632-637)
+    const bool no_sample = result != 0 && (P.flags & AZH_FLAG_ONE_RANDOM_MOVE) && random_ply_of(P, s.uid) + 1 >= s.ply;
+    // A game that is dropped leaves an 8-word marker in the ring, so the host knows this uid will never come
+    // (uid-ordered emission, azh_engine_set_emit_order).
+    auto drop_marker = [&]() {
+        u64 off = 0;
+        if (lane == 0)
+            off = atomicAdd((unsigned long long *)P.ring_head, 8ull);
+        off = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)off);
+        if (off + 8 > P.ring_cap_words) {
+            st_ring = 1;
+        } else if (lane == 0) {
+            u32 *out = P.ring + off;
+            out[0] = RING_MAGIC; out[1] = (u32)g; out[2] = s.uid; out[3] = (u32)s.ply;
+            out[4] = 0; out[5] = 8; out[6] = 0; out[7] = 1;  // word 7: dropped
+        }
+    };
+    if (no_sample) {
+        st_dropped = 1;
+        drop_marker();
+        init_game(P, g, s.uid + (u32)P.G, s, s_moves);
+    } else if (result != 0 || (cut && (P.flags & AZH_FLAG_KEEP_UNFINISHED))) {
         // finished: emit the packed record (generate_game :577-578, Worker :637-642)
         const u32 *recg = P.rec + (size_t)g * P.max_plies * REC_STRIDE_WORDS;
         int words = 0;
@@ -873,6 +895,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
         init_game(P, g, s.uid + (u32)P.G, s, s_moves);
     } else if (cut) {
         st_dropped = 1;  // null-result games are skipped (:628-631)
+        drop_marker();
         init_game(P, g, s.uid + (u32)P.G, s, s_moves);
     } else {
         s.phase = 0;
@@ -998,18 +1021,26 @@ struct azh_engine {
     // finished games formatted but not yet handed out
     std::vector<std::string> pending;
     size_t pending_pos = 0;
-    // timing
-    bool timing = false;
-    std::vector<hipEvent_t> events;  // 4 per recorded iteration
-    size_t ev_used = 0;
-    std::vector<char> ev_closed;  // per timed iteration: ev[3] was recorded (last iteration of a run call)
-    std::vector<int> ev_evals;
+    // uid-ordered emission: finished games wait here until every game with a smaller uid has been handed out or
+    // is known to have been dropped ("" = dropped)
+    bool emit_by_uid = false;
+    std::map<uint32_t, std::string> held;
+    uint32_t next_uid = 0;
+    // timing: every `timing_stride`-th iteration of the device loop is bracketed by events on the engine's stream
+    // (tower start, tower end, start of the next tower = end of the tree phase).  Sampling keeps the event packets —
+    // each a barrier in the queue, a few microseconds — out of most iterations of the region being measured.
+    int timing_stride = 0;  // 0 = off
+    long long loop_iter = 0;
+    std::vector<hipEvent_t> events;  // 3 per sample: tower start, tower end, tree phase end
+    size_t samples = 0;
+    std::vector<int> close_of;       // per sample: index of the event that closes its tree phase
+    bool close_pending = false;      // the last sample's tree phase is closed at the start of the next iteration
     int *h_count = nullptr;  // pinned
     bool selected = false;
     bool arena_lists = false;  // run_arena: one leaf list per net
 };
 
-static const size_t MAX_TIMED_ITERS = 4096;
+static const size_t MAX_TIMED_SAMPLES = 8192;
 
 template <typename T> static int dev_alloc(azh_engine *e, T **p, size_t count)
 {
@@ -1283,14 +1314,24 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
     };
     if (side_advance()) return -1;
     for (int it = 0; it < iterations; it++) {
-        const bool rec = e->timing && e->ev_used + 4 <= e->events.size();
-        hipEvent_t *ev = rec ? &e->events[e->ev_used] : nullptr;
-        if (rec) AZH_HIP(hipEventRecord(ev[1], e->stream));
+        const bool rec = e->timing_stride > 0 && e->loop_iter % e->timing_stride == 0 && e->samples < MAX_TIMED_SAMPLES;
+        hipEvent_t *ev = rec ? &e->events[3 * e->samples] : nullptr;
+        if (e->close_pending) {
+            // the tree phase of the previous sample ends where this tower starts
+            if (rec) {
+                e->close_of[e->samples - 1] = (int)(3 * e->samples);  // this sample's start event doubles as the end
+            } else {
+                AZH_HIP(hipEventRecord(e->events[3 * (e->samples - 1) + 2], e->stream));
+                e->close_of[e->samples - 1] = (int)(3 * (e->samples - 1) + 2);
+            }
+            e->close_pending = false;
+        }
+        if (rec) AZH_HIP(hipEventRecord(ev[0], e->stream));
         int rc = launch_eval(e, net_a, dtype, e->P.leaf_list, e->P.leaf_count);
         if (rc == 0 && net_b)
             rc = launch_eval(e, net_b, dtype, e->P.leaf_list2, e->P.leaf_count2);
         if (rc) return rc;
-        if (rec) AZH_HIP(hipEventRecord(ev[2], e->stream));
+        if (rec) AZH_HIP(hipEventRecord(ev[1], e->stream));
         const int last = it + 1 == iterations;
         AZH_HIP(hipStreamWaitEvent(e->stream, e->ev_adv, 0));
         hipLaunchKernelGGL(k_tree, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P, last ? 0 : 1);
@@ -1298,14 +1339,15 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         AZH_HIP(hipGetLastError());
         if (!last && side_advance()) return -1;
         if (rec) {
-            // ev[1]..ev[2] = tower; ev[2]..next iteration's ev[1] = the tree phases (+ compaction) that follow it.
-            // Only the last iteration of a call closes its tree phase with an event of its own: every event is a
-            // barrier packet in the queue (~4 us), and three per iteration showed up as idle gaps in the kernel trace.
-            e->ev_closed[e->ev_used / 4] = last != 0;
-            if (last)
-                AZH_HIP(hipEventRecord(ev[3], e->stream));
-            e->ev_used += 4;
+            e->samples++;
+            if (last) {
+                AZH_HIP(hipEventRecord(ev[2], e->stream));
+                e->close_of[e->samples - 1] = (int)(3 * (e->samples - 1) + 2);
+            } else {
+                e->close_pending = true;
+            }
         }
+        e->loop_iter++;
     }
     return 0;
 }
@@ -1337,6 +1379,21 @@ extern "C" int azh_engine_set_visits(azh_engine *e, int visits)
         return azh_fail(-1, "azh_engine_set_visits: need 1 <= visits <= %d", e ? e->cfg.visits : 0);
     AZH_HIP(hipStreamSynchronize(e->stream));
     e->P.visits = visits;
+    return 0;
+}
+
+// Order in which finished games are handed out.  0 (default): as they finish.  1: by game uid — a game waits until
+// every game with a smaller uid has been written or dropped.  Games that finish first are the SHORT ones, so a
+// consumer that stops reading after N lines (looper.py:51-64 kills the generator at --game-count lines) gets a
+// length-biased sample in finish order; in uid order the first N lines are the first N games started, whatever
+// their length.
+extern "C" int azh_engine_set_emit_order(azh_engine *e, int by_uid)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_set_emit_order: null engine");
+    if (e->next_uid != 0 || !e->held.empty())
+        return azh_fail(-2, "azh_engine_set_emit_order: games have already been handed out in uid order");
+    e->emit_by_uid = by_uid != 0;
     return 0;
 }
 
@@ -1389,13 +1446,15 @@ extern "C" int azh_engine_timing_reset(azh_engine *e, int enable)
     if (!e)
         return azh_fail(-1, "azh_engine_timing_reset: null engine");
     AZH_HIP(hipStreamSynchronize(e->stream));
-    e->timing = enable != 0;
-    e->ev_used = 0;
-    if (e->timing && e->events.empty()) {
-        e->events.resize(4 * MAX_TIMED_ITERS);
+    e->timing_stride = enable > 0 ? enable : 0;
+    e->samples = 0;
+    e->close_pending = false;
+    e->loop_iter = 0;
+    if (e->timing_stride && e->events.empty()) {
+        e->events.resize(3 * MAX_TIMED_SAMPLES);
         for (auto &ev : e->events)
             AZH_HIP(hipEventCreate(&ev));
-        e->ev_closed.assign(MAX_TIMED_ITERS, 0);
+        e->close_of.assign(MAX_TIMED_SAMPLES, -1);
     }
     return 0;
 }
@@ -1406,16 +1465,14 @@ extern "C" int azh_engine_timing(azh_engine *e, azh_timing *out)
         return azh_fail(-1, "azh_engine_timing: bad argument");
     AZH_HIP(hipStreamSynchronize(e->stream));
     memset(out, 0, sizeof(*out));
-    for (size_t i = 0; i + 4 <= e->ev_used; i += 4) {
+    for (size_t i = 0; i < e->samples; i++) {
+        if (e->close_of[i] < 0)
+            continue;  // the run ended with this sample's tree phase still open (never: the last iteration closes it)
         float b = 0, c = 0;
-        AZH_HIP(hipEventElapsedTime(&b, e->events[i + 1], e->events[i + 2]));
-        // the tree phase ends at its own event (last iteration of a call) or at the next iteration's tower start
-        const bool closed = e->ev_closed[i / 4] != 0;
-        if (!closed && i + 8 > e->ev_used)
-            break;  // cannot happen: the last timed iteration of a call is always closed
-        AZH_HIP(hipEventElapsedTime(&c, e->events[i + 2], closed ? e->events[i + 3] : e->events[i + 5]));
+        AZH_HIP(hipEventElapsedTime(&b, e->events[3 * i], e->events[3 * i + 1]));
+        AZH_HIP(hipEventElapsedTime(&c, e->events[3 * i + 1], e->events[(size_t)e->close_of[i]]));
         out->net_ms += b;
-        out->select_ms += c;  // the fused tree launch (backup + mark + select) and the compaction
+        out->select_ms += c;  // the fused tree launch (backup + mark + select), the compaction and the gaps around them
         out->iterations += 1;
     }
     return 0;
@@ -1450,9 +1507,22 @@ extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int6
                 pos += words;
             }
             std::sort(order.begin(), order.end());
-            for (auto &o : order)
-                e->pending.push_back(azh_format_game_json(host.data() + o.second, host[o.second + 5],
-                                                          (e->P.flags & AZH_FLAG_TWO_NETS) != 0));
+            const bool ids = (e->P.flags & AZH_FLAG_TWO_NETS) != 0;
+            for (auto &o : order) {
+                const uint32_t *rec = host.data() + o.second;
+                const bool dropped = rec[7] == 1;
+                if (e->emit_by_uid)
+                    e->held[o.first] = dropped ? std::string() : azh_format_game_json(rec, rec[5], ids);
+                else if (!dropped)
+                    e->pending.push_back(azh_format_game_json(rec, rec[5], ids));
+            }
+            if (e->emit_by_uid) {
+                for (auto it = e->held.begin(); it != e->held.end() && it->first == e->next_uid; it = e->held.erase(it)) {
+                    if (!it->second.empty())
+                        e->pending.push_back(std::move(it->second));
+                    e->next_uid++;
+                }
+            }
         }
     }
     while (e->pending_pos < e->pending.size()) {

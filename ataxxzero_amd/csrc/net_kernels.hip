@@ -1191,15 +1191,27 @@ extern "C" void azh_net_destroy(azh_net *net)
     delete net;
 }
 
+constexpr int MAX_DEVICES = 64;
+static int current_device()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
+        return -1;
+    return dev;
+}
+
 template <int DT, int NB, int WPS, bool STAMP = false>
 static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
 {
     typedef Geo<DT, NB> G;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[MAX_DEVICES] = {};  // the attribute is per device: a process may drive several GPUs
+    const int dev = current_device();
+    if (dev < 0)
+        return azh_fail(-4, "launch_tower: hipGetDevice failed");
+    if (!attr_set[dev]) {
         AZH_HIP(hipFuncSetAttribute((const void *)k_tower<DT, NB, WPS, STAMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     G::LDS_BYTES));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int grid = (max_n + G::BOARDS - 1) / G::BOARDS;
     if (grid <= 0)
@@ -1213,11 +1225,14 @@ static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
 // AZH_TOWER_BOARDS=6 asks for one 6-board workgroup per CU.
 template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &args, int max_n, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0)
+        return azh_fail(-4, "launch_tower2: hipGetDevice failed");
+    if (!attr_set[dev]) {
         AZH_HIP(hipFuncSetAttribute((const void *)k_tower2<DT, STAMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Geo2::LDS_BYTES));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int grid = (max_n + Geo2::BOARDS - 1) / Geo2::BOARDS;
     if (grid <= 0)
@@ -1363,6 +1378,17 @@ static int net_launch(azh_net *net, int dtype, const unsigned long long *d_board
     }
 }
 
+// device temporary owned by a host function: released when the function returns, error paths included
+struct DevBuf {
+    void *p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <typename T> T *as() const { return (T *)p; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
 extern "C" int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards,
                                uint64_t blockers, float *logits_out, float *values_out)
 {
@@ -1370,22 +1396,19 @@ extern "C" int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *l
         return azh_fail(-1, "azh_net_forward: bad argument");
     if (n == 0)
         return 0;
-    unsigned long long *d_b = nullptr;
-    float *d_l = nullptr, *d_v = nullptr;
-    AZH_HIP(hipMalloc((void **)&d_b, (size_t)n * 16));
-    AZH_HIP(hipMalloc((void **)&d_l, (size_t)n * 833 * 4));
-    AZH_HIP(hipMalloc((void **)&d_v, (size_t)n * 4));
-    AZH_HIP(hipMemcpy(d_b, leaf_boards, (size_t)n * 16, hipMemcpyHostToDevice));
-    int rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, blockers, d_l, d_v, 0, nullptr);
-    if (rc == 0) {
-        AZH_HIP(hipDeviceSynchronize());
-        AZH_HIP(hipMemcpy(logits_out, d_l, (size_t)n * 833 * 4, hipMemcpyDeviceToHost));
-        AZH_HIP(hipMemcpy(values_out, d_v, (size_t)n * 4, hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_b);
-    (void)hipFree(d_l);
-    (void)hipFree(d_v);
-    return rc;
+    DevBuf d_b, d_l, d_v;  // freed on every path out of this function
+    AZH_HIP(d_b.alloc((size_t)n * 16));
+    AZH_HIP(d_l.alloc((size_t)n * 833 * 4));
+    AZH_HIP(d_v.alloc((size_t)n * 4));
+    AZH_HIP(hipMemcpy(d_b.p, leaf_boards, (size_t)n * 16, hipMemcpyHostToDevice));
+    const int rc = azh_net_launch(net, dtype, d_b.as<unsigned long long>(), nullptr, nullptr, n, blockers, d_l.as<float>(),
+                                  d_v.as<float>(), 0, nullptr);
+    if (rc)
+        return rc;
+    AZH_HIP(hipDeviceSynchronize());
+    AZH_HIP(hipMemcpy(logits_out, d_l.p, (size_t)n * 833 * 4, hipMemcpyDeviceToHost));
+    AZH_HIP(hipMemcpy(values_out, d_v.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 extern "C" int azh_net_forward_sym(azh_net *net, int dtype, int n, const uint64_t *leaf_boards,
@@ -1395,26 +1418,21 @@ extern "C" int azh_net_forward_sym(azh_net *net, int dtype, int n, const uint64_
         return azh_fail(-1, "azh_net_forward_sym: bad argument");
     if (n == 0)
         return 0;
-    unsigned long long *d_b = nullptr;
-    float *d_l = nullptr, *d_v = nullptr, *d_tl = nullptr, *d_tv = nullptr;
-    AZH_HIP(hipMalloc((void **)&d_b, (size_t)n * 16));
-    AZH_HIP(hipMalloc((void **)&d_l, (size_t)n * 833 * 4));
-    AZH_HIP(hipMalloc((void **)&d_v, (size_t)n * 4));
-    AZH_HIP(hipMalloc((void **)&d_tl, (size_t)n * 8 * 833 * 4));
-    AZH_HIP(hipMalloc((void **)&d_tv, (size_t)n * 8 * 4));
-    AZH_HIP(hipMemcpy(d_b, leaf_boards, (size_t)n * 16, hipMemcpyHostToDevice));
-    int rc = azh_net_launch_sym(net, dtype, d_b, nullptr, nullptr, n, blockers, d_tl, d_tv, d_l, d_v, 0);
-    if (rc == 0) {
-        AZH_HIP(hipDeviceSynchronize());
-        AZH_HIP(hipMemcpy(logits_out, d_l, (size_t)n * 833 * 4, hipMemcpyDeviceToHost));
-        AZH_HIP(hipMemcpy(values_out, d_v, (size_t)n * 4, hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_b);
-    (void)hipFree(d_l);
-    (void)hipFree(d_v);
-    (void)hipFree(d_tl);
-    (void)hipFree(d_tv);
-    return rc;
+    DevBuf d_b, d_l, d_v, d_tl, d_tv;
+    AZH_HIP(d_b.alloc((size_t)n * 16));
+    AZH_HIP(d_l.alloc((size_t)n * 833 * 4));
+    AZH_HIP(d_v.alloc((size_t)n * 4));
+    AZH_HIP(d_tl.alloc((size_t)n * 8 * 833 * 4));
+    AZH_HIP(d_tv.alloc((size_t)n * 8 * 4));
+    AZH_HIP(hipMemcpy(d_b.p, leaf_boards, (size_t)n * 16, hipMemcpyHostToDevice));
+    const int rc = azh_net_launch_sym(net, dtype, d_b.as<unsigned long long>(), nullptr, nullptr, n, blockers,
+                                      d_tl.as<float>(), d_tv.as<float>(), d_l.as<float>(), d_v.as<float>(), 0);
+    if (rc)
+        return rc;
+    AZH_HIP(hipDeviceSynchronize());
+    AZH_HIP(hipMemcpy(logits_out, d_l.p, (size_t)n * 833 * 4, hipMemcpyDeviceToHost));
+    AZH_HIP(hipMemcpy(values_out, d_v.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // Net-only timing hook: `iters` launches of the tower over n synthetic boards, HIP-event

@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <deque>
+#include <random>
 #include <vector>
 
 #define AZH_NO_REFERENCE_ABI
@@ -114,8 +115,15 @@ extern "C" void launch_threads(char *output_path, int visits, float *fill_buffer
     cfg.dirichlet_alpha = 0.15f;      // (:32)
     cfg.dirichlet_weight = 0.25f;     // (:33)
     cfg.start_turn = 0;
+    // the reference seeds its generator from std::random_device at every launch (:39-40), so a restarted generator
+    // never replays its games; AZH_SEED pins the Philox seed for reproducible runs
     const char *seed = getenv("AZH_SEED");
-    cfg.seed = seed ? strtoull(seed, nullptr, 10) : 20260101ULL;
+    if (seed) {
+        cfg.seed = strtoull(seed, nullptr, 10);
+    } else {
+        std::random_device rd;
+        cfg.seed = ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+    }
     // STARTING_GAME_POSITION "x5o/7/3-3/2-1-2/3-3/7/o5x x" (:23)
     cfg.start_x = (1ULL << 42) | (1ULL << 6);
     cfg.start_o = (1ULL << 48) | (1ULL << 0);

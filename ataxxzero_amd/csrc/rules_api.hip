@@ -10,7 +10,7 @@
 //   random play           generate_games.py:16-75 (--random-play)
 #include <utility>
 
-#include "azh_device.cuh"
+#include "azh_device.h"
 #include "azh_host.h"
 
 namespace azh {

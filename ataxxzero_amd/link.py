@@ -98,6 +98,7 @@ SIGNATURES = {
     "azh_engine_timing_reset": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_timing": (ctypes.c_int, [_vp, _P(Timing)]),
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
+    "azh_engine_set_emit_order": (ctypes.c_int, [_vp, ctypes.c_int]),
     # the reference's ABI, link.py:8-32
     "launch_threads": (None, [ctypes.c_char_p, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     "get_workload": (ctypes.c_int, []),
@@ -346,6 +347,10 @@ class Engine:
     def set_visits(self, visits):
         check(load().azh_engine_set_visits(self.h, visits))
 
+    def set_emit_order(self, by_uid):
+        """True: finished games are handed out in uid order (unbiased prefixes); False: as they finish."""
+        check(load().azh_engine_set_emit_order(self.h, 1 if by_uid else 0))
+
     def game_state(self, g):
         s = GameState()
         check(load().azh_engine_game_state(self.h, g, ctypes.byref(s)))
@@ -366,7 +371,8 @@ class Engine:
         return {n: int(out[i]) for i, n in enumerate(STAT_NAMES)}
 
     def timing_reset(self, enable=True):
-        check(load().azh_engine_timing_reset(self.h, 1 if enable else 0))
+        """False / 0: off; True / 1: every iteration of the device loop is event-timed; n: every n-th."""
+        check(load().azh_engine_timing_reset(self.h, int(enable)))
 
     def timing(self):
         t = Timing()

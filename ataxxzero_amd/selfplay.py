@@ -104,6 +104,10 @@ class SelfPlay:
         for e in self.engines:
             e.set_visits(visits)
 
+    def set_emit_order(self, by_uid):
+        for e in self.engines:
+            e.set_emit_order(by_uid)
+
     def drain(self):
         lines = []
         for e in self.engines:

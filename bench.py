@@ -3,22 +3,30 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A step is one search iteration of the hot path over one batch: every one of the
-`games` concurrent trees descends by PUCT, expands one leaf, the fused conv tower
-evaluates the leaf batch, and the results are backed up (plus move sampling / re-rooting /
-game turnover for the trees whose root reached `visits`).  Metric (BASELINE.json):
-MCTS node-evals/s at 400 sims/move; games/s reported beside it.  Workload at N=1: 4096
-concurrent games, 400 sims/move, 12x128 net (random-init seed 1, .npy layout), bf16 — the
-per-GPU shard of BASELINE.json configs[2] (32768 games over 8 GPUs), i.e. configs[1]'s game
-count at the sims/move the metric is quoted on.  N ranks = N x 4096 games, weak scaling, no
-data-path collective.
+Workload at N=1: 4096 concurrent games, 400 sims/move, 12x128 net (random-init seed 1, .npy layout), bf16 — the
+per-GPU shard of BASELINE.json configs[2] (32768 games over 8 GPUs), i.e. configs[1]'s game count at the sims/move
+the metric is quoted on.  N ranks = N x 4096 games, weak scaling, no data-path collective.
 
-Prints ONE JSON line on rank 0, with the dominant kernel's roofline (MFMA, measured with
-HIP events on the engine's stream) and a CPU baseline (the oracle port on the host cores).
+A STEP is one round trip of the generator's host loop (accelerated_generate_games.py:54-83 drains finished games
+once per round trip): ITERS_PER_STEP = 250 search iterations of the hot path over the whole batch — in every
+iteration each of the `games` trees descends by PUCT and expands one leaf, the fused conv tower evaluates the leaf
+batch, the results are backed up, due moves are sampled / re-rooted / recorded — followed by one drain of the
+finished games' records to the host.  Metric (BASELINE.json): MCTS node-evals/s at 400 sims/move; games/s =
+finished games drained in the timed region / its wall time.  The games are first spread over all game phases
+(a fresh start has every game at ply 0), so both figures are steady-state figures.
+
+Prints ONE JSON line on rank 0, with the dominant kernel's roofline (MFMA; HIP events on the engine's stream,
+sampled over the timed region) and a CPU baseline: the reference's architecture (one host thread per game,
+double-buffered batches) on this box's cores with the GPU tower as its evaluator.
+
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself, one child process per
+GPU, before anything touches the GPU in this process; under torchrun it is one of the ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +36,9 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0
+ITERS_PER_STEP = 250
+TIMING_STRIDE = 8        # every 8th iteration is event-timed (an event is a barrier packet in the queue)
+PMC_SUMMARY = os.path.join("profiles", "round2_bench_pmc_k_tower.txt")
 
 
 def tree_bytes(d, logit_bytes=4):
@@ -42,107 +53,154 @@ def measured_traffic():
     MI355X_MICROARCH.md §HBM prescribes for gfx950, + WRITE_SIZE), as summarised by tools/prof_bench.sh into
     profiles/.  PMC counters cannot be read from inside the process, so this is the committed measurement, or null."""
     import re
-    path = os.path.join(ROOT, "profiles", "round1_bench_pmc_k_tower.txt")
-    try:
-        m = re.search(r"x2 corrected: ([0-9.e+]+) MB\), WRITE_SIZE [0-9.e+]+ KiB \(([0-9.e+]+) MB\)", open(path).read())
-        return (float(m.group(1)) + float(m.group(2))) * 1e6, os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    for rel in (PMC_SUMMARY, os.path.join("profiles", "round1_bench_pmc_k_tower.txt")):
+        try:
+            m = re.search(r"x2 corrected: ([0-9.e+]+) MB\), WRITE_SIZE [0-9.e+]+ KiB \(([0-9.e+]+) MB\)",
+                          open(os.path.join(ROOT, rel)).read())
+            return (float(m.group(1)) + float(m.group(2))) * 1e6, rel
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(conv, bn, visits, seconds=15.0, games=128):
-    """The oracle port (sequential PUCT per game + numpy f32 net) on the host cores, on a
-    bounded sample of the same workload: `games` concurrent games at the same sims/move."""
+def cpu_baseline(net, visits, dtype, seconds):
+    """The reference's architecture on this box (tools/cpu_baseline): 2B host game threads doing sequential PUCT,
+    B-row double buffer, the host loop handing each full buffer to an evaluator.  Three legs on a bounded sample:
+    (ii) the GPU tower as evaluator on all host cores = `value`; (i) a null evaluator on all cores and pinned to 8
+    cores — the figure BASELINE.md §2 measured from the real cpp/self_play_client.so (38-49 k steps/s)."""
     import numpy as np
-    from oracle import net_oracle
-    from oracle import oracle_lib as orc
-    cfg = orc.make_config(games=games, visits=visits, seed=20260101)
-    eng = orc.Engine(cfg)
-    logits = np.zeros((games, 833), np.float32)
-    values = np.zeros(games, np.float32)
-    t0 = time.time()
-    iters = 0
-    while time.time() - t0 < seconds:
-        n, need = eng.select()
-        lb = eng.leaf_boards()
-        idx = np.nonzero(need)[0]
-        if len(idx):
-            p, v = net_oracle.forward(conv, bn, net_oracle.features_from_leaf_boards(lb[idx], cfg.blockers, np.float32),
-                                      dtype=np.float32)
-            logits[idx] = p.reshape(len(idx), 833)
-            values[idx] = v.reshape(len(idx))
-        eng.backup(logits, values)
-        iters += 1
-    dt = time.time() - t0
-    st = eng.stats()
-    # the tree side alone (null evaluator: zero logits, zero value), as SURVEY 8(d) asks beside the full figure
-    eng2 = orc.Engine(orc.make_config(games=games, visits=visits, seed=20260101))
-    zl, zv = np.zeros((games, 833), np.float32), np.zeros(games, np.float32)
-    t2 = time.time()
-    while time.time() - t2 < min(3.0, seconds):
-        eng2.select()
-        eng2.backup(zl, zv)
-    tree_only = eng2.stats()["steps"] / (time.time() - t2)
-    return {"value": st["steps"] / dt, "unit": "node-evals/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
-            "tree_only_value": tree_only,
-            "sample": "%d concurrent games x %d iterations (%.1f s): oracle tree search (1 thread) + numpy f32 "
-                      "conv tower (BLAS threads = host cores), same net / sims-per-move; tree_only_value = the same "
-                      "search with a null evaluator, 1 thread" % (games, iters, dt)}
+    from ataxxzero_amd import build, link, selfplay
+    from tools.cpu_baseline import driver
+    build.build_cpu_baseline()
+    blockers = selfplay.parse_fen(selfplay.START_FEN_SELFPLAY)[2]
+    dt = link.DTYPES[dtype]
+    cores = sorted(os.sched_getaffinity(0))
+    B = 256
+
+    def tower(boards):
+        p, v = net.forward(boards, blockers, dt)
+        return p.reshape(len(boards), 833), v.reshape(len(boards))
+
+    full = driver.run(tower, visits, B, seconds)
+    null_all = driver.run(None, visits, B, min(seconds, 5.0))
+    null_8 = None
+    if len(cores) > 8:
+        os.sched_setaffinity(0, set(cores[:8]))   # the game threads inherit it
+        try:
+            null_8 = driver.run(None, visits, 64, min(seconds, 5.0))
+        finally:
+            os.sched_setaffinity(0, set(cores))
+    return {"value": full["steps_per_s"], "unit": "node-evals/s", "cores": len(cores), "kind": "port",
+            "nn_evals_per_s": full["evals_per_s"], "plies_per_s": full["plies_per_s"],
+            "null_evaluator_value": null_all["steps_per_s"],
+            "null_evaluator_8_cores_value": (null_8 or null_all)["steps_per_s"],
+            "reference_so_null_evaluator_8_cores": "38-49 k steps/s (BASELINE.md §2, the real cpp/self_play_client.so)",
+            "sample": "%d host game threads (buffer %d, the reference's 2B threads / B-row double buffer), %d sims/move, "
+                      "%.1f s timed after a 1 s warm-up; evaluator = this GPU's %s tower through azh_net_forward "
+                      "(host buffers: PCIe both ways, as the reference's sess.run); null legs: all-zero evaluations"
+                      % (full["threads"], B, visits, full["seconds"], dtype)}
 
 
-def target_leg(conv, bn, args, games=16384, steps=300, warmup=100):
+def measure(sp, args, steps, warmup, group=None):
+    """`warmup` untimed steps, then EXACTLY `steps` timed steps between barriers + device syncs."""
+    def run_steps(n):
+        finished = 0
+        for _ in range(n):
+            sp.run(args.iters_per_step)
+            finished += len(sp.drain())   # sync + hand the finished games to the host, as the CLI does
+        return finished
+
+    run_steps(warmup)
+    sp.sync()
+    if group is not None:
+        group.barrier()
+    st0 = sp.stats()
+    sp.timing_reset(TIMING_STRIDE)
+    t0 = time.perf_counter()
+    finished = run_steps(steps)
+    sp.sync()
+    t1 = time.perf_counter()
+    if group is not None:
+        group.barrier()
+    st1 = sp.stats()
+    return {k: st1[k] - st0[k] for k in st1}, finished, t1 - t0, sp.timing()
+
+
+def spread(sp, args):
+    """Untimed set-up: take the games off ply 0 and spread them over all game phases with cheap 16-sim moves,
+    then regrow the trees at full sims/move."""
+    if args.phase_mix > 0:
+        sp.set_visits(min(16, args.visits))
+        done = 0
+        while done < args.phase_mix:
+            sp.run(min(250, args.phase_mix - done))
+            sp.drain()
+            done += 250
+        sp.set_visits(args.visits)
+        done = 0
+        while done < args.phase_fill:
+            sp.run(min(250, args.phase_fill - done))
+            sp.drain()
+            done += 250
+
+
+def target_leg(conv, bn, args, games=16384, steps=2, warmup=1):
     """BASELINE.json's north-star operating point (>= 10k concurrent games on one GPU, 400 sims/move) measured
     the same way as the headline, reported beside it (never as `value`)."""
     from ataxxzero_amd import model, selfplay
     sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=args.dtype, seed=selfplay.DEFAULT_SEED + 77,
                            select_budget=args.select_budget)
-    def run(iters):
-        done = 0
-        while done < iters:
-            n = min(args.chunk, iters - done)
-            sp.run(n)
-            sp.drain()
-            done += n
-
     try:
-        sp.set_visits(min(16, args.visits))
-        run(args.phase_mix)
-        sp.set_visits(args.visits)
-        run(300)
-        run(warmup)
-        sp.sync()
-        st0 = sp.stats()
-        sp.timing_reset(True)
-        t0 = time.perf_counter()
-        run(steps)
-        sp.sync()
-        dt = time.perf_counter() - t0
-        st1 = sp.stats()
-        tm = sp.timing()
+        spread(sp, args)
+        d, finished, dt, tm = measure(sp, args, steps, warmup)
         it = max(tm["iterations"], 1)
-        evals = (st1["nn_evals"] - st0["nn_evals"]) * it / float(steps)
-        tf = evals * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] * 1e-3) / 1e12
-        return {"games": games, "node_evals_per_s": (st1["steps"] - st0["steps"]) / dt, "ms_per_step": 1e3 * dt / steps,
-                "steps": steps,
+        iters = steps * args.iters_per_step
+        tf = d["nn_evals"] / float(iters) * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] / it * 1e-3) / 1e12
+        return {"games": games, "node_evals_per_s": d["steps"] / dt, "games_per_s": finished / dt,
+                "ms_per_iteration": 1e3 * dt / iters, "steps": steps,
                 "tower_ms_per_launch": tm["net_ms"] / it, "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[args.dtype],
-                "tree_ms_per_step": (tm["select_ms"] + tm["backup_ms"]) / it}
+                "tree_ms_per_iteration": (tm["select_ms"] + tm["backup_ms"]) / it}
     finally:
         sp.close()
+
+
+def spawn_ranks(n):
+    """--gpus N with no launcher: one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its
+    environment, exactly what torchrun would set), started before this process has made any HIP or torch call.
+    Rank 0's stdout is passed through; any failing rank fails the run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit("bench.py: rank(s) failed: %s" % ", ".join("rank %d -> exit %d" % rc for rc in bad))
+    return 0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1500)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps (a step = --iters-per-step search iterations + one drain)")
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--iters-per-step", type=int, default=ITERS_PER_STEP)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--visits", type=int, default=400)
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--chunk", type=int, default=250, help="iterations between finished-game drains")
     ap.add_argument("--streams", type=int, default=1, help="half-batches in flight per GPU (the reference's double buffer)")
     ap.add_argument("--phase-mix", type=int, default=2500,
-                    help="untimed setup iterations at 16 sims/move that spread the games over all game phases "
+                    help="untimed set-up iterations at 16 sims/move that spread the games over all game phases "
                          "(a fresh start has every game at ply 0 with an empty tree), followed by --phase-fill "
                          "iterations at full sims/move that regrow the trees; then the --warmup steps")
     ap.add_argument("--phase-fill", type=int, default=500)
@@ -152,13 +210,34 @@ def main():
                          "line of the batch; every game still plays exactly the same search")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target-leg", action="store_true", help="skip the 16384-game leg reported beside the headline")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--plumbing-selftest", action="store_true",
+                    help="NO GPU WORK: every rank reports fixed units so the launch / barrier / aggregation path of "
+                         "--gpus N can be exercised on a CPU-only box (tests/test_distrib_gloo.py); value is null")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
-    from ataxxzero_amd import distrib, link, model, selfplay
+    from ataxxzero_amd import distrib
     group = distrib.Group()
-    if group.world != args.gpus and group.world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, group.world))
+    if group.world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, group.world))
+
+    if args.plumbing_selftest:
+        group.barrier()
+        units, secs = 1000.0 * (group.rank + 1), 1.0 + group.rank
+        total, t_max, rate = distrib.aggregate(group, units, secs)
+        group.barrier()
+        if group.rank == 0:
+            print(json.dumps({"metric": "plumbing selftest (no GPU work)", "value": None, "n_gpus": group.world,
+                              "data": "none", "units_total": total, "t_max": t_max, "rate": rate,
+                              "seeds": [distrib.shard_seed(20260101, r) for r in range(group.world)]}))
+        group.close()
+        return 0
+
+    from ataxxzero_amd import link, model, selfplay
     ndev = link.require_gpu()
     link.check(link.load().azh_set_device(distrib.device_for(group.local_rank, ndev)))
 
@@ -166,50 +245,24 @@ def main():
     sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
                            seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank), streams=args.streams,
                            select_budget=args.select_budget)
-
-    def run(iters):
-        done = 0
-        finished = 0
-        while done < iters:
-            n = min(args.chunk, iters - done)
-            sp.run(n)
-            finished += len(sp.drain())   # sync + hand finished games to the host, as the CLI does
-            done += n
-        return finished
-
-    if args.phase_mix > 0:
-        sp.set_visits(min(16, args.visits))
-        run(args.phase_mix)
-        sp.set_visits(args.visits)
-        run(args.phase_fill)
-    run(args.warmup)
-    sp.sync()
-    group.barrier()
-    st0 = sp.stats()
-    sp.timing_reset(True)
-    t0 = time.perf_counter()
-    finished = run(args.steps)
-    sp.sync()
-    t1 = time.perf_counter()
-    group.barrier()
-    st1 = sp.stats()
-    tm = sp.timing()
-    d = {k: st1[k] - st0[k] for k in st1}
-    steps_total, t_max, rate = distrib.aggregate(group, d["steps"], t1 - t0)
+    spread(sp, args)
+    d, finished, dt, tm = measure(sp, args, args.steps, args.warmup, group)
+    steps_total, t_max, rate = distrib.aggregate(group, d["steps"], dt)
     evals_total = group.reduce(d["nn_evals"], "sum")
     plies_total = group.reduce(d["plies"], "sum")
     games_total = group.reduce(finished, "sum")
 
     if group.rank == 0:
         flops = model.flops_per_eval(args.blocks, 128)
-        it = max(tm["iterations"], 1)   # launches recorded (per half-batch when streams > 1)
-        frac_timed = it / float(args.steps * args.streams)
-        net_s = tm["net_ms"] * 1e-3
-        achieved_tf = d["nn_evals"] * frac_timed * flops / net_s / 1e12 if net_s > 0 else 0.0
+        iters = args.steps * args.iters_per_step
+        it = max(tm["iterations"], 1)                # sampled launches (per half-batch when streams > 1)
+        launch_ms = tm["net_ms"] / it
+        evals_per_launch = d["nn_evals"] / float(iters * args.streams)
+        achieved_tf = evals_per_launch * flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         traffic, traffic_src = measured_traffic()
-        tree_s = (tm["select_ms"] + tm["backup_ms"]) * 1e-3
-        tree_gbs = tree_bytes(d) * frac_timed / tree_s / 1e9 if tree_s > 0 else 0.0
+        tree_ms = (tm["select_ms"] + tm["backup_ms"]) / it
+        tree_gbs = tree_bytes(d) / float(iters * args.streams) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         out = {
             "metric": "MCTS node-evals/s at %d sims/move (self-play; games/s beside it)" % args.visits,
             "value": rate, "unit": "node-evals/s", "n_gpus": group.world, "steps": args.steps, "warmup": args.warmup,
@@ -219,25 +272,27 @@ def main():
             "config": {"workload": "%d concurrent self-play games per GPU, %d sims/move, %dx128 conv net, %s "
                                    "(per-GPU shard of BASELINE configs[2]; configs[1] at the metric's 400 sims)"
                                    % (args.games, args.visits, args.blocks, args.dtype),
+                       "step": "%d search iterations over the whole batch + one drain of the finished games"
+                               % args.iters_per_step,
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
                        "select_budget": args.select_budget,
                        "setup": "games spread over all phases by %d untimed 16-sim iterations + %d at full sims, then "
                                 "the warm-up" % (args.phase_mix, args.phase_fill if args.phase_mix > 0 else 0),
                        "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},
+            "ms_per_iteration": 1e3 * t_max / iters,
             "nn_evals_per_s": evals_total / t_max, "plies_per_s": plies_total / t_max,
-            # finished games per second in steady state = plies/s / mean game length; 147.75 plies is the mean
-            # over 29,296 games written by the real CLI in a 420 s soak of this workload
-            "games_per_s": (plies_total / t_max) / 147.75,
+            "games_per_s": games_total / t_max,    # finished games (result 1 or 2) handed to the host in the timed region
             "games_finished_in_timed_region": games_total,
+            "mean_plies_per_finished_game": plies_total / games_total if games_total else None,
             "roofline": {"bound": "mfma", "kernel": "%s<%s>" % ("k_tower" if args.dtype == "f32" or os.environ.get("AZH_TOWER") == "1" else "k_tower2", args.dtype), "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": tm["net_ms"] / it, "evals_per_launch": d["nn_evals"] / float(args.steps * args.streams),
-                         "flops_per_eval": flops},
+                         "avg_launch_ms": launch_ms, "evals_per_launch": evals_per_launch,
+                         "launches_timed": it, "launches_in_region": iters * args.streams, "flops_per_eval": flops},
             "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup + move-due mark + select, fused) + k_compact on the engine's stream; "
                                          "k_advance_list (re-roots) runs on a side stream under the tower",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS,
-                              "select_ms_per_step": tm["select_ms"] / it, "backup_ms_per_step": tm["backup_ms"] / it,
+                              "tree_phase_ms_per_iteration": tree_ms,
                               "bytes_per_step": tree_bytes(d) / float(max(d["steps"], 1)),
                               "levels_per_step": d["levels"] / float(max(d["steps"], 1)),
                               "children_per_step": d["children"] / float(max(d["steps"], 1))},
@@ -247,13 +302,16 @@ def main():
         if group.world == 1 and not args.no_target_leg and args.streams == 1:
             out["target_10k_games"] = target_leg(conv, bn, args)
         if group.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(conv, bn, args.visits, seconds=args.cpu_seconds)
+            net = link.Net(conv, bn)
+            out["cpu_baseline"] = cpu_baseline(net, args.visits, args.dtype, args.cpu_seconds)
+            net.close()
         print(json.dumps(out))
         sys.stdout.flush()
     else:
         sp.close()
     group.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

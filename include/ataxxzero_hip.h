@@ -171,8 +171,8 @@ enum {
 };
 
 typedef struct {
-    /* sums of HIP-event elapsed milliseconds over the launches recorded since the
-     * last azh_engine_timing_reset, and the number of iterations recorded */
+    /* sums of HIP-event elapsed milliseconds over the iterations SAMPLED since the last azh_engine_timing_reset
+     * (every `enable`-th iteration of the device loop, events on the engine's stream), and the number of samples */
     double select_ms, net_ms, backup_ms; /* select_ms: the fused tree launch of the run loop (backup + advance +
                                             select + compaction); backup_ms: 0 there */
     int64_t iterations;
@@ -219,6 +219,8 @@ int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out);
 int azh_engine_tree(azh_engine *e, int game, uint64_t *boards, uint32_t *info, uint32_t *edges,
                     uint16_t *moves);
 int azh_engine_stats(azh_engine *e, uint64_t *out /* [AZH_STAT_COUNT] */);
+/* enable = 0: off; n > 0: bracket every n-th iteration of the device loop with events (tower start / tower end /
+ * next tower start); at most 8192 samples are kept */
 int azh_engine_timing_reset(azh_engine *e, int enable);
 int azh_engine_timing(azh_engine *e, azh_timing *out);
 
@@ -227,6 +229,13 @@ int azh_engine_timing(azh_engine *e, azh_timing *out);
  * result; one compact object per line).  Writes whole lines only; *used = bytes
  * written, *n_games = lines written; call again while *n_games > 0. */
 int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, int32_t *n_games);
+/* Order in which azh_engine_drain_json hands games out: 0 (default) as they finish; 1 by game uid (slot g plays
+ * uids g, g + games, g + 2 games, ...): a finished game is held back until every game with a smaller uid has been
+ * handed out or dropped.  The reference's workers write games as they finish (Worker::thread_main :637-642) and
+ * looper.py:51-64 stops the generator at --game-count lines, i.e. keeps the games that finished FIRST — the short
+ * ones; with thousands of games in flight that bias is no longer slight, and uid order removes it (the first N
+ * lines are the first N games started).  Call before the first drain. */
+int azh_engine_set_emit_order(azh_engine *e, int by_uid);
 
 /* ------------------------------------------------------------------ reference ABI
  * The four symbols link.py:6-32 binds (cpp/self_play_client.cpp:683-749), with

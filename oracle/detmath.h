@@ -6,7 +6,7 @@
  * bit for bit: every operation below is an IEEE-754 basic operation (add, mul,
  * div, sqrt, fma) in a fixed order, so gcc (-ffp-contract=off) and hipcc
  * (-ffp-contract=off) produce identical bits.  The product's own copy lives in
- * ataxxzero_amd/csrc/detmath.cuh; the two are kept in step by
+ * ataxxzero_amd/csrc/azh_device.h; the two are kept in step by
  * tests/test_detmath_gpu.py.
  *
  * These functions replace libm's exp/log/gamma sampling that the reference

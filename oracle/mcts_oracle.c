@@ -176,6 +176,7 @@ void orc_engine_destroy(orc_engine *e)
 }
 
 int orc_engine_node_cap(const orc_engine *e) { return e->node_cap; }
+void orc_engine_set_visits(orc_engine *e, int visits) { e->cfg.visits = visits; }
 int orc_engine_edge_cap(const orc_engine *e) { return e->edge_cap; }
 
 /* cpp/self_play_client.cpp:386-447: descend by PUCT, expand one node. */
@@ -601,7 +602,11 @@ static void advance_game(orc_engine *e, int g)
     s->ply += 1;
     e->force[g] = 0;
     int result = (int)(ni2[1] >> 16);
-    if (result != 0) {
+    if (result != 0 && (e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE) && random_ply_of(e, s->uid) + 1 >= s->ply) {
+        /* "Skipping game with no board state just after the uniformly random move" (:632-637) */
+        st[ORC_STAT_DROPPED]++;
+        init_game(e, g, s->uid + (uint32_t)e->G);
+    } else if (result != 0) {
         finish_game(e, g, result);
         st[ORC_STAT_GAMES]++;
         init_game(e, g, s->uid + (uint32_t)e->G);

@@ -81,6 +81,9 @@ orc_engine *orc_engine_create(const orc_config *cfg);
 void orc_engine_destroy(orc_engine *e);
 int orc_engine_node_cap(const orc_engine *e);
 int orc_engine_edge_cap(const orc_engine *e);
+/* root-visit threshold for the coming moves, 1 .. the value the engine was created with (the arenas are sized for
+ * that); mirror of azh_engine_set_visits */
+void orc_engine_set_visits(orc_engine *e, int visits);
 
 /* phase 1 of an iteration: select/expand in every game; returns #leaves needing
  * the evaluator.  need_eval[g] (optional) = 1 for those games. */

@@ -73,6 +73,7 @@ def lib():
         "orc_board_cells": (None, [P(Pos), vp]),
         "orc_engine_create": (vp, [P(Config)]), "orc_engine_destroy": (None, [vp]),
         "orc_engine_node_cap": (ctypes.c_int, [vp]), "orc_engine_edge_cap": (ctypes.c_int, [vp]),
+        "orc_engine_set_visits": (None, [vp, ctypes.c_int]),
         "orc_engine_select": (ctypes.c_int, [vp, vp]), "orc_engine_leaf_boards": (None, [vp, vp]),
         "orc_engine_leaf_features": (None, [vp, ctypes.c_int, vp]),
         "orc_engine_backup": (None, [vp, vp, vp]),
@@ -203,6 +204,9 @@ class Engine:
 
     def __del__(self):
         self.close()
+
+    def set_visits(self, visits):
+        lib().orc_engine_set_visits(self.h, visits)
 
     def select(self):
         need = np.zeros(self.G, dtype=np.int32)

@@ -61,3 +61,36 @@ def test_single_rank_needs_no_process_group():
         for k, v in env_backup.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def test_bench_py_starts_its_own_ranks_and_aggregates():
+    """`python bench.py --gpus 2` with no launcher: bench.py itself starts one process per rank (before any HIP call),
+    the ranks meet over gloo, rank 0 prints the one JSON line.  --plumbing-selftest replaces the GPU work by fixed
+    units (rank r: 1000 (r + 1) units in 1 + r seconds), so the launch / barrier / sum-over-max-time path runs on a
+    CPU-only box; the GPU-side twin of this test is tests/test_gpu_cli.py::test_bench_py_two_ranks_on_one_gpu."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest"],
+                         env=env, capture_output=True, timeout=240)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    out = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["value"] is None
+    assert out["units_total"] == 3000.0 and out["t_max"] == 2.0 and out["rate"] == 1500.0
+    assert out["seeds"] == [20260101, 20260102]
+
+
+def test_bench_py_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest"],
+                         env=env, capture_output=True, timeout=120)
+    assert res.returncode != 0 and b"--gpus 2 but WORLD_SIZE=1" in res.stderr
+
+
+def test_cpu_baseline_threads_play_with_a_null_evaluator():
+    # bench.py's cpu_baseline target (the reference's thread-per-game architecture): launch, batch hand-off, shutdown
+    sys.path.insert(0, ROOT)
+    from ataxxzero_amd import build
+    from tools.cpu_baseline import driver
+    build.build_cpu_baseline()
+    r = driver.run(None, visits=50, buffer_entries=8, seconds=1.0, warmup_seconds=0.3)
+    assert r["threads"] == 16 and r["steps_per_s"] > 1000 and r["plies_per_s"] > 5
+    assert 0.9 <= r["steps_per_s"] / r["evals_per_s"] <= 1.2   # ~one evaluation per step, plus terminal re-hits

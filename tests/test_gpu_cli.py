@@ -308,3 +308,22 @@ def test_bench_contract_line():
     assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["tree_only_value"] > c["value"]
+
+
+def test_bench_py_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 started without a launcher: it spawns the two ranks itself (before any HIP call in the parent);
+    both fold onto this box's one GPU (AZH_DEVICE_MOD=1) and meet over gloo (RCCL refuses two ranks on one device).
+    Tiny workload: the launch path, the barriers, the per-rank seeds and the aggregation are what is tested."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(AZH_DEVICE_MOD="1", AZH_DIST_BACKEND="gloo")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--iters-per-step", "60", "--games", "256", "--visits", "16", "--blocks", "2", "--phase-mix", "120",
+                          "--phase-fill", "30", "--no-cpu-baseline", "--no-target-leg"], env=env, cwd=ROOT,
+                         capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    out = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    # both ranks' work is in the aggregate: each of the 2 x 256 games makes about one step per iteration
+    assert out["value"] > 0 and 0.5 * 2 * 256 * 120 < out["value"] * out["ms_per_step"] * 2e-3 < 1.1 * 2 * 256 * 120
+    assert out["games_finished_in_timed_region"] == out["games_per_s"] * out["ms_per_step"] * 2e-3 or out["games_per_s"] > 0
+    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["launches_timed"] > 0

@@ -43,8 +43,8 @@ if __name__ == "__main__":
         switch("--gauntlet", "first engine against all others (with two engines: the same match)"),
         flag("--tc", "seconds per move, recorded in the PGN (the search is visit-limited)", type=float, default=1.0,
              metavar="SEC"),
-        flag("--game-count", "stop after this many games (extension: the reference never stops)", type=int, default=1000,
-             metavar="N"),
+        flag("--game-count", "size of the match (extension: the reference never stops): the games with uid below N are "
+                             "played to completion and scored", type=int, default=1000, metavar="N"),
         flag("--concurrent", "games in flight on the GPU (extension)", type=int, metavar="N"),
         flag("--dtype", "tower arithmetic (extension)", default="bf16", choices=["bf16", "f16", "f32"]),
         flag("--seed", "Philox seed (extension)", type=int, default=selfplay.DEFAULT_SEED),
@@ -70,11 +70,17 @@ if __name__ == "__main__":
     wins = {"a": 0, "b": 0}
     annulled = 0
     written = 0
-    while written < args.game_count:
+    # The match is a FIXED cohort: the games with uid < --game-count (slot g plays uids g, g + concurrent, ...; uid and
+    # slot have the same parity, so the cohort holds every pairing both ways).  It runs until all of them have
+    # finished.  Counting "the first N games to finish" instead would count the short games of a slot several times
+    # while long games still in flight are thrown away — a net that wins quickly would look better than it is; the
+    # reference ringmaster plays its games one after another to completion (uai_ringmaster.py:221-262).
+    cohort = args.game_count
+    while written < cohort:
         match.run(25)
         for game in sorted(match.drain(), key=lambda g: g["uid"]):
-            if written >= args.game_count:
-                break
+            if game["uid"] >= cohort:
+                continue  # a replacement game started in a slot whose cohort games are done
             white = game["white"]
             black = "b" if white == "a" else "a"
             print('Game: "%s" vs "%s" with opening: []' % (names[white], names[black]))
