@@ -81,8 +81,12 @@ def cpu_baseline(net, visits, dtype, seconds):
         p, v = net.forward(boards, blockers, dt)
         return p.reshape(len(boards), 833), v.reshape(len(boards))
 
-    full = driver.run(tower, visits, B, seconds)
-    null_all = driver.run(None, visits, B, min(seconds, 5.0))
+    # the evaluator leg gets the buffer size that suits it best: a larger batch amortises the per-call cost of the
+    # host-buffer evaluator (the reference's default is 128 rows, accelerated_generate_games.py:20)
+    legs = [driver.run(tower, visits, b, seconds / 2.0) for b in (256, 1024)]
+    full = max(legs, key=lambda r: r["steps_per_s"])
+    B = full["buffer_entries"]
+    null_all = driver.run(None, visits, 256, min(seconds, 5.0))
     null_8 = None
     if len(cores) > 8:
         os.sched_setaffinity(0, set(cores[:8]))   # the game threads inherit it
@@ -92,6 +96,7 @@ def cpu_baseline(net, visits, dtype, seconds):
             os.sched_setaffinity(0, set(cores))
     return {"value": full["steps_per_s"], "unit": "node-evals/s", "cores": len(cores), "kind": "port",
             "nn_evals_per_s": full["evals_per_s"], "plies_per_s": full["plies_per_s"],
+            "evaluator_legs": {str(r["buffer_entries"]): r["steps_per_s"] for r in legs},
             "null_evaluator_value": null_all["steps_per_s"],
             "null_evaluator_8_cores_value": (null_8 or null_all)["steps_per_s"],
             "reference_so_null_evaluator_8_cores": "38-49 k steps/s (BASELINE.md §2, the real cpp/self_play_client.so)",
@@ -127,10 +132,10 @@ def measure(sp, args, steps, warmup, group=None):
 
 
 def spread(sp, args):
-    """Untimed set-up: take the games off ply 0 and spread them over all game phases with cheap 16-sim moves,
-    then regrow the trees at full sims/move."""
+    """Untimed set-up: take the games off ply 0 and spread them over all game phases with cheap 4-sim moves (several
+    game generations, so the slots' ages decorrelate), then regrow the trees at full sims/move."""
     if args.phase_mix > 0:
-        sp.set_visits(min(16, args.visits))
+        sp.set_visits(min(4, args.visits))
         done = 0
         while done < args.phase_mix:
             sp.run(min(250, args.phase_mix - done))
@@ -199,10 +204,11 @@ def main():
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--streams", type=int, default=1, help="half-batches in flight per GPU (the reference's double buffer)")
-    ap.add_argument("--phase-mix", type=int, default=2500,
-                    help="untimed set-up iterations at 16 sims/move that spread the games over all game phases "
-                         "(a fresh start has every game at ply 0 with an empty tree), followed by --phase-fill "
-                         "iterations at full sims/move that regrow the trees; then the --warmup steps")
+    ap.add_argument("--phase-mix", type=int, default=4000,
+                    help="untimed set-up iterations at 4 sims/move (about 700 plies, several game generations) that "
+                         "spread the games over all game phases (a fresh start has every game at ply 0 with an empty "
+                         "tree), followed by --phase-fill iterations at full sims/move that regrow the trees; then the "
+                         "--warmup steps")
     ap.add_argument("--phase-fill", type=int, default=500)
     ap.add_argument("--select-budget", type=int, default=48,
                     help="tree levels per select launch and game (azh_config.select_budget; 0 = unlimited): deeper "
@@ -276,7 +282,7 @@ def main():
                                % args.iters_per_step,
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
                        "select_budget": args.select_budget,
-                       "setup": "games spread over all phases by %d untimed 16-sim iterations + %d at full sims, then "
+                       "setup": "games spread over all phases by %d untimed 4-sim iterations + %d at full sims, then "
                                 "the warm-up" % (args.phase_mix, args.phase_fill if args.phase_mix > 0 else 0),
                        "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},

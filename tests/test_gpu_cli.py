@@ -293,7 +293,7 @@ def test_accelerated_generate_games_extension_flags(tmp_path):
 def test_bench_contract_line():
     """bench.py prints ONE JSON line with the driver's keys, the roofline and the cpu_baseline objects."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--games", "96", "--visits", "8", "--blocks", "1",
-                          "--steps", "30", "--warmup", "10", "--phase-mix", "40", "--phase-fill", "10", "--chunk", "10",
+                          "--steps", "30", "--warmup", "10", "--iters-per-step", "10", "--phase-mix", "40", "--phase-fill", "10",
                           "--cpu-seconds", "1.5", "--no-target-leg"], cwd=ROOT, capture_output=True, timeout=400)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
@@ -304,10 +304,15 @@ def test_bench_contract_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 10 and d["value"] > 0 and d["vs_baseline"] is None
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"]
+    assert abs(d["ms_per_step"] - 10 * d["ms_per_iteration"]) < 1e-6 * d["ms_per_step"]
+    # games/s is the count of games handed to the host in the timed region over its wall time, nothing derived
+    assert abs(d["games_per_s"] * d["ms_per_step"] * 30e-3 - d["games_finished_in_timed_region"]) < 1e-6
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0 < r["launches_timed"] <= r["launches_in_region"] == 300
+    assert r["avg_launch_ms"] < d["ms_per_iteration"]
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["tree_only_value"] > c["value"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["null_evaluator_value"] > 0
 
 
 def test_bench_py_two_ranks_on_one_gpu():

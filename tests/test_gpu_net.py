@@ -3,7 +3,8 @@ model.py (oracle/net_oracle.py) on identical boards.
 
 Tolerances: f32 MFMA path <= 1e-5 absolute on logits and value (BASELINE.json
 north_star); bf16 / f16 paths are reduced-precision by construction and are bounded
-against the f32 path (5e-2 / 1e-2 absolute on O(1) logits), reported, not claimed."""
+against the f32 path (2e-3 / 3e-4 absolute on logits of scale 0.1: three times the measured error), reported, not
+claimed."""
 import numpy as np
 import pytest
 
@@ -52,7 +53,9 @@ def test_first_boards_of_partial_tiles_and_empty_batch():
     assert p.shape == (0, 7, 7, 17)
 
 
-@pytest.mark.parametrize("dtype,tol", [(link.DTYPE_BF16, 5e-2), (link.DTYPE_F16, 1e-2)])
+# tolerances = 3x the error measured on this net (tools/precision_in_the_loop.py, profiles/round2_precision_in_the_loop.json:
+# max |dlogit| 6.9e-4 bf16 / 9.6e-5 f16 on logits of scale 0.1; what that does to the search is reported there)
+@pytest.mark.parametrize("dtype,tol", [(link.DTYPE_BF16, 2e-3), (link.DTYPE_F16, 3e-4)])
 def test_reduced_precision_tower_tracks_f32(dtype, tol):
     conv, bn = model.random_init(12, 128, seed=1)
     lb = sample_leaf_boards(50, 5, BLOCK4_MASK)
@@ -99,7 +102,7 @@ def test_full_size_launch_is_position_independent(dtype):
     big = np.concatenate([base] * 17)[:16384]
     p, v = net.forward(big, BLOCK4_MASK, dtype)
     assert np.isfinite(p).all() and np.isfinite(v).all() and (np.abs(v) <= 1).all()
-    tol = {link.DTYPE_BF16: 3e-2, link.DTYPE_F16: 6e-3, link.DTYPE_F32: 0.0}[dtype]
+    tol = {link.DTYPE_BF16: 2e-3, link.DTYPE_F16: 3e-4, link.DTYPE_F32: 0.0}[dtype]
     for rep in range(1, 16):
         lo = rep * 1021
         n = min(1021, 16384 - lo)

@@ -68,7 +68,7 @@ def compare(ref, other):
         eps = 0.5 / n_a.sum()             # half a visit: a move one search never tried does not make KL infinite
         kls.append(float(np.sum(p * np.log((p + eps) / (q + eps)))))
         tvs.append(float(0.5 * np.abs(p - q).sum()))
-    return {"top1_agreement": float(np.mean(top1)), "kl_mean": float(np.mean(kls)), "kl_p95": float(np.percentile(kls, 95)),
+    return {"top1_agreement": float(np.mean(top1)), "kl_mean": float(np.mean(kls)), "kl_median": float(np.median(kls)), "kl_p95": float(np.percentile(kls, 95)),
             "kl_max": float(np.max(kls)), "tv_mean": float(np.mean(tvs))}
 
 
