@@ -50,6 +50,8 @@ struct EngineParams {
     int start_turn;
     u32 flags;
     int select_budget;  // tree levels per select launch and game (0 = unlimited), azh_config.select_budget
+    int *opening_until;  // azh_engine_set_opening_sims: slot g plays `opening_visits` sims/move until one of its games
+    int opening_visits;  // reaches ply opening_until[g]; the entry is then cleared (null = off)
     azh_game_state *gs;
     int *force;
     int *adv_list;   // games whose move is due (phase 2), appended by mark_game, consumed by k_advance_list
@@ -935,7 +937,17 @@ __device__ inline void mark_game(const EngineParams &P, int g)
     if (lane_id() != 0)
         return;
     const azh_game_state s = P.gs[g];
-    if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= P.visits || P.force[g] != 0)) {
+    int need = P.visits;
+    if (P.opening_until) {
+        const int until = P.opening_until[g];
+        if (until > 0) {
+            if (s.ply < until)
+                need = P.opening_visits;
+            else
+                P.opening_until[g] = 0;  // the slot has reached its age: full-price searches from here on
+        }
+    }
+    if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= need || P.force[g] != 0)) {
         P.gs[g].phase = 2;
         P.adv_list[atomicAdd(P.adv_count, 1)] = g;
     }
@@ -1018,6 +1030,7 @@ struct azh_engine {
     float *d_feat = nullptr;
     float *d_sym_logits = nullptr, *d_sym_values = nullptr;  // AZH_FLAG_SYMMETRY_AVG scratch
     u64 *d_stat_out = nullptr;
+    int *d_opening = nullptr;
     // finished games formatted but not yet handed out
     std::vector<std::string> pending;
     size_t pending_pos = 0;
@@ -1394,6 +1407,28 @@ extern "C" int azh_engine_set_emit_order(azh_engine *e, int by_uid)
     if (e->next_uid != 0 || !e->held.empty())
         return azh_fail(-2, "azh_engine_set_emit_order: games have already been handed out in uid order");
     e->emit_by_uid = by_uid != 0;
+    return 0;
+}
+
+// Cheap openings: slot g needs only `visits_low` root visits per move until one of its games reaches ply until_ply[g]
+// (games that end earlier are followed by another cheap game); from that ply on, and in every later game of the slot,
+// the configured sims/move apply.  A measurement set-up hook: bench.py puts every slot at the age a generator that has
+// been running for a long time would show, without paying full-price searches for the plies before it; until_ply =
+// NULL switches it off.
+extern "C" int azh_engine_set_opening_sims(azh_engine *e, const int32_t *until_ply, int visits_low)
+{
+    if (!e || (until_ply && (visits_low < 1 || visits_low > e->cfg.visits)))
+        return azh_fail(-1, "azh_engine_set_opening_sims: need 1 <= visits_low <= %d", e ? e->cfg.visits : 0);
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    if (!until_ply) {
+        e->P.opening_until = nullptr;
+        return 0;
+    }
+    if (!e->d_opening && dev_alloc(e, &e->d_opening, (size_t)e->P.G))
+        return -1;
+    AZH_HIP(hipMemcpy(e->d_opening, until_ply, (size_t)e->P.G * 4, hipMemcpyHostToDevice));
+    e->P.opening_until = e->d_opening;
+    e->P.opening_visits = visits_low;
     return 0;
 }
 

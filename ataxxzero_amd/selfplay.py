@@ -89,12 +89,10 @@ class SelfPlay:
         self.games = games
 
     def run(self, iterations):
-        if len(self.engines) == 1:
-            self.engine.run(self.net, iterations, self.dtype)
-            return
-        for _ in range(iterations):
-            for e in self.engines:
-                e.run(self.net, 1, self.dtype)
+        # every engine enqueues its whole run on its own streams (the calls are asynchronous): the half-batches then
+        # advance independently on the GPU, one's tree phase and tower tail filled by the other's tower
+        for e in self.engines:
+            e.run(self.net, iterations, self.dtype)
 
     def sync(self):
         for e in self.engines:
@@ -103,6 +101,12 @@ class SelfPlay:
     def set_visits(self, visits):
         for e in self.engines:
             e.set_visits(visits)
+
+    def set_opening_sims(self, until_ply, visits_low):
+        lo = 0
+        for e in self.engines:
+            e.set_opening_sims(None if until_ply is None else until_ply[lo:lo + e.G], visits_low)
+            lo += e.G
 
     def set_emit_order(self, by_uid):
         for e in self.engines:

@@ -131,22 +131,36 @@ def measure(sp, args, steps, warmup, group=None):
     return {k: st1[k] - st0[k] for k in st1}, finished, t1 - t0, sp.timing()
 
 
-def spread(sp, args):
-    """Untimed set-up: take the games off ply 0 and spread them over all game phases with cheap 4-sim moves (several
-    game generations, so the slots' ages decorrelate), then regrow the trees at full sims/move."""
-    if args.phase_mix > 0:
-        sp.set_visits(min(4, args.visits))
+def stationary_ages(n, seed):
+    """Ages (plies already played) of the game slots of a generator that has been running for a long time: for a
+    renewal process the age distribution is P(age = a) ~ P(L > a), with L the game length.  L comes from one complete
+    generation of real games at this workload (profiles/round2_game_lengths.json, tools/length_histogram.py: 4096
+    games, mean 152.4 plies)."""
+    import numpy as np
+    with open(os.path.join(ROOT, "profiles", "round2_game_lengths.json")) as f:
+        hist = np.asarray(json.load(f)["histogram_plies"], dtype=np.float64)
+    survival = hist[::-1].cumsum()[::-1] - hist          # survival[a] = #games longer than a plies
+    p = survival / survival.sum()
+    return np.random.default_rng(seed).choice(len(p), size=n, p=p).astype(np.int32)
+
+
+def spread(sp, args, seed):
+    """Untimed set-up: a fresh start has every game at ply 0 with an empty tree — nothing like the state the generator
+    works in.  Every slot is given an age drawn from the stationary age distribution (stationary_ages) and plays 4-sim
+    moves until it is that old (azh_engine_set_opening_sims); then --phase-fill iterations at full sims/move regrow
+    the trees.  `--phase-mix 0` skips all of it."""
+    if args.phase_mix <= 0:
+        return None
+    ages = stationary_ages(sp.games, seed)
+    sp.set_opening_sims(ages, min(4, args.visits))
+    for budget in (args.phase_mix, args.phase_fill):
         done = 0
-        while done < args.phase_mix:
-            sp.run(min(250, args.phase_mix - done))
+        while done < budget:
+            sp.run(min(250, budget - done))
             sp.drain()
             done += 250
-        sp.set_visits(args.visits)
-        done = 0
-        while done < args.phase_fill:
-            sp.run(min(250, args.phase_fill - done))
-            sp.drain()
-            done += 250
+    sp.set_opening_sims(None, 1)
+    return {"mean_age_plies": float(ages.mean()), "max_age_plies": int(ages.max())}
 
 
 def target_leg(conv, bn, args, games=16384, steps=2, warmup=1):
@@ -156,7 +170,7 @@ def target_leg(conv, bn, args, games=16384, steps=2, warmup=1):
     sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=args.dtype, seed=selfplay.DEFAULT_SEED + 77,
                            select_budget=args.select_budget)
     try:
-        spread(sp, args)
+        spread(sp, args, selfplay.DEFAULT_SEED + 77)
         d, finished, dt, tm = measure(sp, args, steps, warmup)
         it = max(tm["iterations"], 1)
         iters = steps * args.iters_per_step
@@ -204,11 +218,11 @@ def main():
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--streams", type=int, default=1, help="half-batches in flight per GPU (the reference's double buffer)")
-    ap.add_argument("--phase-mix", type=int, default=4000,
-                    help="untimed set-up iterations at 4 sims/move (about 700 plies, several game generations) that "
-                         "spread the games over all game phases (a fresh start has every game at ply 0 with an empty "
-                         "tree), followed by --phase-fill iterations at full sims/move that regrow the trees; then the "
-                         "--warmup steps")
+    ap.add_argument("--phase-mix", type=int, default=3000,
+                    help="untimed set-up iterations in which every slot plays 4-sim moves up to an age drawn from the "
+                         "stationary age distribution of the generator (profiles/round2_game_lengths.json), followed by "
+                         "--phase-fill iterations at full sims/move that regrow the trees; then the --warmup steps.  "
+                         "0 = start cold (every game at ply 0)")
     ap.add_argument("--phase-fill", type=int, default=500)
     ap.add_argument("--select-budget", type=int, default=48,
                     help="tree levels per select launch and game (azh_config.select_budget; 0 = unlimited): deeper "
@@ -251,7 +265,7 @@ def main():
     sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
                            seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank), streams=args.streams,
                            select_budget=args.select_budget)
-    spread(sp, args)
+    ages = spread(sp, args, distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank))
     d, finished, dt, tm = measure(sp, args, args.steps, args.warmup, group)
     steps_total, t_max, rate = distrib.aggregate(group, d["steps"], dt)
     evals_total = group.reduce(d["nn_evals"], "sum")
@@ -282,8 +296,9 @@ def main():
                                % args.iters_per_step,
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
                        "select_budget": args.select_budget,
-                       "setup": "games spread over all phases by %d untimed 4-sim iterations + %d at full sims, then "
-                                "the warm-up" % (args.phase_mix, args.phase_fill if args.phase_mix > 0 else 0),
+                       "setup": ("slots aged to the generator's stationary age distribution (mean %.0f plies) by %d untimed "
+                                 "iterations of 4-sim moves + %d at full sims, then the warm-up"
+                                 % (ages["mean_age_plies"], args.phase_mix, args.phase_fill)) if ages else "cold start",
                        "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},
             "ms_per_iteration": 1e3 * t_max / iters,

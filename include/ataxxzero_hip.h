@@ -212,6 +212,12 @@ int azh_engine_sync(azh_engine *e);
  * value the engine was created with */
 int azh_engine_set_visits(azh_engine *e, int visits);
 
+/* Measurement set-up hook: slot g needs only visits_low root visits per move until one of its games reaches ply
+ * until_ply[g] ([games] host array; NULL switches the hook off; a game that ends earlier is followed by another cheap
+ * one); from that ply on the configured sims/move apply.  bench.py uses it to put every slot at the age a long-running
+ * generator would find it at. */
+int azh_engine_set_opening_sims(azh_engine *e, const int32_t *until_ply, int visits_low);
+
 int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out);
 /* arena dump: boards [n_nodes][2] u64, info [n_nodes][4] u32
  * (first_edge, n_edges | result << 16, 0, terminal value bits), edges

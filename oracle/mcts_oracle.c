@@ -41,6 +41,8 @@ struct orc_engine {
     uint64_t *stats;
     blob *done_head, *done_tail;
     int done_count;
+    int32_t *opening_until;  /* orc_engine_set_opening_sims */
+    int opening_visits;
 };
 
 static inline uint64_t *NB(const orc_engine *e, int a, int g) { return e->node_board + ((size_t)(a * e->G + g) * e->node_cap) * 2; }
@@ -172,11 +174,21 @@ void orc_engine_destroy(orc_engine *e)
     if (!e) return;
     while (e->done_head) { blob *n = e->done_head->next; free(e->done_head); e->done_head = n; }
     free(e->gs); free(e->force); free(e->path); free(e->node_board); free(e->node_info);
-    free(e->edge); free(e->edge_move); free(e->rec); free(e->stats); free(e);
+    free(e->edge); free(e->edge_move); free(e->rec); free(e->stats); free(e->opening_until); free(e);
 }
 
 int orc_engine_node_cap(const orc_engine *e) { return e->node_cap; }
 void orc_engine_set_visits(orc_engine *e, int visits) { e->cfg.visits = visits; }
+void orc_engine_set_opening_sims(orc_engine *e, const int32_t *until_ply, int visits_low)
+{
+    free(e->opening_until);
+    e->opening_until = NULL;
+    if (until_ply) {
+        e->opening_until = (int32_t *)malloc(sizeof(int32_t) * (size_t)e->G);
+        memcpy(e->opening_until, until_ply, sizeof(int32_t) * (size_t)e->G);
+        e->opening_visits = visits_low;
+    }
+}
 int orc_engine_edge_cap(const orc_engine *e) { return e->edge_cap; }
 
 /* cpp/self_play_client.cpp:386-447: descend by PUCT, expand one node. */
@@ -642,11 +654,19 @@ void orc_engine_backup(orc_engine *e, const float *logits, const float *values)
         default:
             break;
         }
+        /* cheap openings (orc_engine_set_opening_sims): looked at for every game in every iteration, as the engine does */
+        int need = e->cfg.visits;
+        if (e->opening_until && e->opening_until[g] > 0) {
+            if (s->ply < e->opening_until[g])
+                need = e->opening_visits;
+            else
+                e->opening_until[g] = 0; /* the slot has reached its age */
+        }
         if (s->leaf_kind == ORC_LEAF_DESCENT)
             continue; /* parked descent: nothing to back up, and the tree must stay as it is */
         s->leaf_kind = ORC_LEAF_NONE;
         /* while (root.all_edge_visits < global_visits) step(); (:522-525): the move is due */
-        if (s->phase == ORC_PHASE_SEARCH && (s->root_visits >= e->cfg.visits || e->force[g]))
+        if (s->phase == ORC_PHASE_SEARCH && (s->root_visits >= need || e->force[g]))
             s->phase = ORC_PHASE_ADVANCING;
     }
 }

@@ -361,3 +361,18 @@ def test_uid_ordered_emission_is_an_unbiased_prefix():
     first_finishers = [len(r["entry"]["moves"]) for r in o_games[:len(want) // 2]]
     prefix = [len(e["moves"]) for e in want[:len(want) // 2]]
     assert np.mean(first_finishers) < np.mean(prefix) + 1e-9 and np.mean(first_finishers) < np.mean(lengths_all)
+
+
+def test_cheap_openings_hook_matches_oracle():
+    # azh_engine_set_opening_sims (bench.py's set-up): slot g's first game plays 3-sim moves up to a per-slot ply
+    oe, ge = make_pair(games=24, visits=20, max_plies=200, seed=8)
+    until = (np.arange(24) * 7) % 60
+    for e in (oe, ge):
+        e.set_opening_sims(until, 3)
+    run_lockstep(oe, ge, 1500, check_every=97)
+    st = oe.stats()
+    # far more plies than 1500 iterations of 20-sim moves could make: the openings were cheap
+    assert st["plies"] > 24 * 1500 / 21 * 1.5
+    for e in (oe, ge):
+        e.set_opening_sims(None, 1)
+    run_lockstep(oe, ge, 200, check_every=50)
