@@ -84,3 +84,56 @@ def drive(engine_select, engine_leaves, engine_backup, iterations):
         engine_select()
         logits, values = synthetic_evals_distinct(engine_leaves())
         engine_backup(logits, values)
+
+
+# ------------------------------------------------------------------ multi-ply searches with tree reuse
+
+REUSE_FLAGS = orc.FLAG_TIE_FIRST | orc.FLAG_PY_POSTERIOR | orc.FLAG_SAMPLE_POW5   # python engine, trees KEPT across moves
+
+
+def reuse_fixtures():
+    return load_gz("engine_reuse_search.json.gz")
+
+
+def reuse_config(rec):
+    return orc.make_config(games=1, visits=rec["visits"], seed=3, fen_str=rec["fen"], max_plies=400, weight=0.0,
+                           flags=REUSE_FLAGS)
+
+
+def check_edges(tree, want_edges):
+    got, _ = walk_tree(tree)
+    want = {p: (n, w) for p, n, w in want_edges}
+    assert set(got) == set(want), sorted(set(got) ^ set(want))[:5]
+    for p, (n, w) in want.items():
+        assert got[p][0] == n, (p, got[p][0], n)
+        assert abs(got[p][1] - w) <= n * 2e-7 * max(1.0, w), (p, got[p][1], w)
+
+
+def check_reuse_sequence(rec, select, leaves, backup, game_state, tree):
+    """Drive one game slot through the fixture's plies: before every move the tree must be the tree engine.py had when
+    its root reached `visits` visits (inherited visits included), the forced move must be the move played, and after
+    MCTS.play the kept subtree must be the reference's, edge for edge."""
+    ply = checked = 0
+    for _ in range(rec["visits"] * len(rec["plies"]) + 50):
+        select()
+        s = game_state()
+        if s.uid != 0:
+            # the last forced move ended the game (the slot has already restarted): every ply was compared, and the
+            # reference's kept root is that finished position, with nothing under it
+            assert checked == len(rec["plies"]) and rec["kept_edges"] == []
+            return
+        if s.ply > ply:   # this select played the move that was due
+            ply = s.ply
+            if ply == len(rec["plies"]):
+                assert s.root_visits == rec["kept_root_visits"]
+                check_edges(tree(), rec["kept_edges"])
+                return
+        logits, values = synthetic_evals_distinct(leaves())
+        backup(logits, values)
+        s = game_state()
+        if s.phase == 2:   # the move is due: the finished search of this ply
+            want = rec["plies"][s.ply]
+            assert s.root_visits == want["root_visits"], (s.ply, s.root_visits, want["root_visits"])
+            check_edges(tree(), want["edges"])
+            checked += 1
+    raise AssertionError("the fixture's plies were not all played")

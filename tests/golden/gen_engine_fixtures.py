@@ -25,6 +25,8 @@ Writes data-only fixtures next to this script:
                           (MCTSEngine.set_state + genmove(1e6, use_weighted_exponent=5.0) with MAX_STEPS = visits):
                           every edge of the final tree (path, visits, total score), root posterior, the move
                           weights of sample_with_exponential_weight (engine.py:532-548), smallest PUCT margin met
+  engine_reuse_search.json.gz  16 multi-ply searches WITH tree reuse (MCTS.play, engine.py:411-424) whose every move is
+                          forced (one root edge with n >= max/2): per ply the tree before the move, then the kept subtree
   engine_reuse.json       a 12-ply game played the way uai_ringmaster.py drives two engines (one `moves` message per
                           ply -> set_state): root visits found after every set_state (tree reuse never happens)
   train_samples.npz       train.get_sample_from_entries (train.py:43-77) under random.seed(k) on
@@ -288,6 +290,53 @@ def reuse_fixture():
     return plies
 
 
+def reuse_search_fixture():
+    """Multi-ply searches WITH tree reuse, pinned by the reference's own MCTS.play (engine.py:411-424): search until the
+    root has `visits` visits (the C++ generator's rule, cpp/self_play_client.cpp:522 — inherited visits count), take the
+    move sample_with_exponential_weight would return, MCTS.play it (the chosen child's subtree and counts are kept),
+    search again.  Only sequences in which every move is FORCED are kept: exactly one root edge has n >= max/2, so the
+    exponent-5 sample is that move whatever the random number — the engine under test draws from Philox, the
+    reference from `random`, and neither matters."""
+    install(distinct_on_features)
+    recs = []
+    positions = sample_positions(31337, 30, 5)
+    rng = random.Random(9)
+    rng.shuffle(positions)
+    for state in positions:
+        if len(recs) >= 16:
+            break
+        visits = (60, 100, 150)[len(recs) % 3]
+        mcts = engine.MCTS(state.copy())
+        plies = []
+        ok = True
+        for ply in range(4):
+            steps = 0
+            while mcts.root_node.all_edge_visits < visits:
+                if mcts.step() is None:   # terminal root
+                    ok = False
+                    break
+                steps += 1
+            if not ok:
+                break
+            root = mcts.root_node
+            top = max(e.edge_visits for e in root.outgoing_edges.values())
+            forced = [m for m, e in root.outgoing_edges.items() if e.edge_visits >= top * 0.5]
+            if len(forced) != 1:
+                ok = False
+                break
+            move = forced[0]
+            plies.append({"fen": root.board.fen(), "steps": steps, "root_visits": int(root.all_edge_visits),
+                          "move": enc(move), "edges": tree_edges(root)})
+            mcts.play(root.board.to_move, move)
+            if mcts.root_node.board.result() is not None:
+                break
+        if ok and len(plies) >= 3:
+            recs.append({"fen": state.fen(), "visits": visits, "plies": plies,
+                         "kept_root_visits": int(mcts.root_node.all_edge_visits), "kept_edges": tree_edges(mcts.root_node)})
+    dump_gz("engine_reuse_search.json.gz", recs)
+    return recs
+
+
 # ------------------------------------------------------------------ train.py sample pipeline
 
 def train_fixture():
@@ -363,6 +412,9 @@ def main():
     recs = mcts_fixture()
     print("searches:", len(recs), "edges:", sum(len(r["edges"]) for r in recs),
           "min margin: %.3g" % min(r["min_margin"] for r in recs))
+    rr = reuse_search_fixture()
+    print("reuse searches:", len(rr), "plies:", [len(r["plies"]) for r in rr],
+          "inherited visits:", [p["root_visits"] - p["steps"] for r in rr for p in r["plies"][1:]][:12])
     plies = reuse_fixture()
     print("reuse: inherited root visits per ply:", [p["inherited_root_visits"] for p in plies])
     print("train samples:", train_fixture())

@@ -118,3 +118,17 @@ def test_symmetry_average_equals_nn_evals_evaluate():
     assert np.abs(p - want["policy"]).max() <= 1e-6 and np.abs(v.ravel() - want["value"]).max() <= 1e-6
     plain, _ = ev32(feats)
     assert np.abs(plain - want["policy"]).max() > 1e-2  # the average differs from the plain evaluation
+
+
+def test_tree_reuse_across_moves_equals_mcts_play():
+    # engine.MCTS.play (engine.py:411-424) keeps the chosen child's subtree; the searches continue from its counts
+    recs = fx.reuse_fixtures()
+    assert len(recs) == 16
+    inherited = 0
+    for rec in recs:
+        oe = orc.Engine(fx.reuse_config(rec))
+        fx.check_reuse_sequence(rec, oe.select, oe.leaf_boards, oe.backup, lambda: oe.game_state(0), lambda: oe.tree(0))
+        st = oe.stats()
+        assert st["reroot_nodes"] > len(rec["plies"])   # subtrees were kept, not rebuilt
+        inherited += sum(p["root_visits"] - p["steps"] for p in rec["plies"][1:])
+    assert inherited > 1000

@@ -61,3 +61,19 @@ def test_search_reproduces_engine_py_trees():
         assert s.ply == 0 and s.phase == 2
         fx.check_search(rec, ge.tree(0), s)
         ge.close()
+
+
+def test_tree_reuse_across_moves_equals_mcts_play():
+    """advance_game's re-root (breadth-first subtree copy into the other arena) against engine.MCTS.play: 16 four-ply
+    sequences of forced moves; the tree before every move and the kept subtree after the last one, edge for edge."""
+    for rec in fx.reuse_fixtures():
+        ocfg = fx.reuse_config(rec)
+        ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+
+        def backup(logits, values):
+            ge.set_evals(logits, values)
+            ge.backup()
+
+        fx.check_reuse_sequence(rec, ge.select, lambda: ge.leaves()[1], backup, lambda: ge.game_state(0), lambda: ge.tree(0))
+        assert ge.stats()["reroot_nodes"] > len(rec["plies"])
+        ge.close()
