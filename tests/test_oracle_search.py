@@ -132,3 +132,49 @@ def test_select_budget_changes_timing_not_games():
     for uid in common:
         assert base[uid] == slow[uid]
     assert e1.stats()["steps"] < 12000 * 8  # some iterations were spent parked
+
+
+def test_root_noise_is_dirichlet_and_moves_follow_the_visits():
+    """The two random ingredients of the C++ generator that no reference vector can pin (unseeded RNG there) are
+    checked against their DEFINITIONS with third-party statistics: the gamma draws behind the root noise
+    (std::gamma_distribution(0.15, 1), cpp/self_play_client.cpp:252-255) against scipy's Gamma(0.15) by a
+    Kolmogorov-Smirnov test, and the move sampler (:495-506) against the visit counts by a chi-square test."""
+    from scipy import stats
+    g = np.array([orc.lib().orc_probe_gamma(0.15, 12345, uid, 3, uid % 50) for uid in range(20000)], dtype=np.float64)
+    assert (g >= 0).all() and abs(g.mean() - 0.15) < 0.01 and abs(g.var() - 0.15) < 0.02
+    # (the smallest draws underflow to 0 in f32; Gamma(0.15) puts ~1.5 % of its mass below 1e-12)
+    assert stats.kstest(g[g > 1e-12], lambda x: (stats.gamma.cdf(x, 0.15) - stats.gamma.cdf(1e-12, 0.15)) /
+                        (1 - stats.gamma.cdf(1e-12, 0.15))).pvalue > 1e-3
+    # move ~ visits / N: many one-ply games from the same position with a pure-function evaluator and no noise give the same
+    # root visit counts in every slot, so the played moves are i.i.d. samples of that one distribution
+    from tests.helpers import synthetic_evals
+    G = 6000
+    e = orc.Engine(orc.make_config(games=G, visits=60, seed=99, weight=0.0, max_plies=400))
+    tree0 = None
+    while e.stats()["plies"] < G:
+        e.select()
+        e.backup(*synthetic_evals(e.leaf_boards()))
+        if tree0 is None and e.game_state(0).phase == 2:
+            b, info, edges, moves = e.tree(0)
+            first, m = int(info[0, 0]), int(info[0, 1] & 0xFFFF)
+            tree0 = (moves[first:first + m].copy(), edges[first:first + m, 1].astype(np.float64))
+    # the first move of every slot's game is recorded in its ply-0 record: read it back through the kept subtrees' roots
+    played = {}
+    for gme in range(G):
+        s = e.game_state(gme)
+        assert s.ply == 1
+        x = int(e.tree(gme)[0][0, 0]) & ((1 << 63) - 1)
+        played[x] = played.get(x, 0) + 1
+    mv, n = tree0
+    p0 = orc.pos_from_fen(orc.START_FEN_SELFPLAY)
+    expect = {}
+    for m_, cnt in zip(mv, n):
+        q = orc.Pos()
+        q.pieces[0], q.pieces[1], q.blockers, q.turn = p0.pieces[0], p0.pieces[1], p0.blockers, p0.turn
+        orc.lib().orc_makemove(q, int(m_) & 0xFF, int(m_) >> 8)
+        expect[int(q.pieces[0])] = expect.get(int(q.pieces[0]), 0) + cnt / n.sum() * G
+    keys = sorted(k for k, v in expect.items() if v > 0)
+    assert set(played) <= set(keys) and len(keys) >= 4
+    obs = np.array([played.get(k, 0) for k in keys], dtype=np.float64)
+    exp = np.array([expect[k] for k in keys])
+    assert stats.chisquare(obs, exp).pvalue > 1e-3
