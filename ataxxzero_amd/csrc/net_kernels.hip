@@ -582,7 +582,10 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
 #ifndef AZH_RING2
 #define AZH_RING2 2
 #endif
-constexpr int RING2 = AZH_RING2;  // A-fragment ring depth of variant 2 (steps of prefetch distance)
+constexpr int RING2 = AZH_RING2;
+#ifndef AZH_SETPRIO
+#define AZH_SETPRIO 0
+#endif  // A-fragment ring depth of variant 2 (steps of prefetch distance)
 
 template <int DT> struct Mfma16;
 template <> struct Mfma16<AZH_DTYPE_BF16> {
@@ -770,6 +773,9 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             else
                 load_b(b[par ^ 1], cur, ks1, IC<i1>());
             __builtin_amdgcn_sched_barrier(0);
+#if AZH_SETPRIO
+            __builtin_amdgcn_s_setprio(AZH_SETPRIO);  // tuning experiment (tools/tower_variants.sh): MFMA cluster at raised priority
+#endif
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 static_for<0, TPW>([&](auto ct_tag) {
@@ -777,6 +783,9 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
                     if constexpr (!skip_pair(ct, i))
                         acc[t][ct] = Mfma16<DT>::mfma(a[rs][t], b[par][ct], acc[t][ct]);
                 });
+#if AZH_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             load_a(a[rs], step_of(o, j + RING2));
             if constexpr (ks1 == 0) {
 #pragma unroll
