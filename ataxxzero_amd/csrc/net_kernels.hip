@@ -93,19 +93,22 @@ template <> struct Traits<AZH_DTYPE_F32> {
 // BOARDS boards per workgroup.  16-bit types: 6 boards fill one CU's LDS (one workgroup per
 // CU, one wave per SIMD); 3 boards let two workgroups share a CU (two waves per SIMD hide
 // each other's LDS / L2 latency and smooth the tail of the grid).  f32: 3 boards.
-template <int DT, int NB> struct Geo {
+template <int DT, int NB, int FT = F> struct Geo {
     typedef Traits<DT> Tr;
+    static constexpr int FILTERS = FT;                 // channels of the tower (model.py:16; 64 / 128 / 256 are built)
+    static constexpr int OCTF = FT / 32;               // waves per workgroup: one 32-channel output tile each
+    static constexpr int NTHR = 64 * OCTF;
     static constexpr int BOARDS = NB;
     static constexpr int NC = 49 * BOARDS;             // real cells per workgroup
     static constexpr int NT = (NC + 31) / 32;          // 32-cell MFMA column tiles
     static constexpr int Z = 16;                       // zero slots per unit, shared by both images
     static constexpr int NSLOT = 2 * NC + Z;           // slots of one unit: [image 0][zeros][image 1]
     static constexpr int UB = DT == AZH_DTYPE_F32 ? 4 : 16;               // bytes of one unit in one slot
-    static constexpr int NUNIT = F * Tr::ESIZE / UB;                        // units per image
+    static constexpr int NUNIT = FT * Tr::ESIZE / UB;                       // units per image
     static constexpr int CS = NSLOT * UB;              // byte stride between units
     static constexpr int VCELL_OFF = NUNIT * CS;       // f32 value-cell scratch behind the images
     static constexpr int LDS_BYTES = VCELL_OFF + NC * 4;
-    static constexpr int KSTEPS_FULL = F / Tr::KSTEP;  // k-steps per tap, 128-channel input
+    static constexpr int KSTEPS_FULL = FT / Tr::KSTEP; // k-steps per tap, FT-channel input
     static constexpr int KSTEPS_IN = (Tr::KSTEP >= 4) ? 1 : 4 / Tr::KSTEP;  // 4 input planes
     // slot (within a unit) of cell c of image img
     __device__ static int real_slot(int img, int c) { return img * (NC + Z) + c; }
@@ -192,7 +195,7 @@ __device__ inline unsigned long long stamp_now()
     return t;
 }
 
-template <int DT, int NB, int KS, bool STAMP = false>
+template <int DT, int NB, int KS, bool STAMP = false, int FT = F>
 __device__ inline void conv_layer(unsigned char *lds, int in_img, int out_img, bool skip,
                                   const typename Traits<DT>::afrag *__restrict__ wp,
                                   typename Traits<DT>::afrag (&a)[RING], f32x16 &sh, const float *__restrict__ shift_next,
@@ -200,7 +203,7 @@ __device__ inline void conv_layer(unsigned char *lds, int in_img, int out_img, b
                                   unsigned long long *st = nullptr)
 {
     typedef Traits<DT> Tr;
-    typedef Geo<DT, NB> G;
+    typedef Geo<DT, NB, FT> G;
     typedef typename Tr::afrag afrag;
     constexpr int NT = G::NT;
     constexpr int TOTAL = 9 * KS;
@@ -252,10 +255,10 @@ __device__ inline void conv_layer(unsigned char *lds, int in_img, int out_img, b
     };
 
     // A fragments: wave-uniform base + one 32-bit lane offset; the fragment of step s sits
-    // s * OCT KiB further on.
+    // s * (waves per workgroup) KiB further on.
     const char *wbase = reinterpret_cast<const char *>(wp);
     const unsigned lane_off = (unsigned)((wave * 64 + lane) * sizeof(afrag));
-    constexpr size_t STEP_BYTES = (size_t)OCT * 64 * sizeof(afrag);
+    constexpr size_t STEP_BYTES = (size_t)G::OCTF * 64 * sizeof(afrag);
     // Steps >= TOTAL run on into the next layer's fragments (layers are contiguous in the
     // packed buffer, which is padded at the end): the ring is already warm when the next
     // layer starts.
@@ -418,11 +421,12 @@ __device__ inline void conv_layer(unsigned char *lds, int in_img, int out_img, b
     if constexpr (STAMP) st[2] = stamp_now();
 }
 
-template <int DT, int NB, int WPS, bool STAMP = false>
-__global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
+template <int DT, int NB, int WPS, bool STAMP = false, int FT = F>
+__global__ __launch_bounds__(64 * (FT / 32), WPS) void k_tower(TowerArgs A)
 {
     typedef Traits<DT> Tr;
-    typedef Geo<DT, NB> G;
+    typedef Geo<DT, NB, FT> G;
+    constexpr int OCT = G::OCTF, NTHREADS = G::NTHR, F = FT;  // shadow the 128-filter constants of the fast path
     typedef typename Tr::afrag afrag;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -512,18 +516,18 @@ __global__ __launch_bounds__(NTHREADS, WPS) void k_tower(TowerArgs A)
     }
     if constexpr (STAMP) st[1] = stamp_now();
     // (the shift table has one spare row so the last layer's look-ahead stays in bounds)
-    conv_layer<DT, NB, G::KSTEPS_IN, STAMP>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
+    conv_layer<DT, NB, G::KSTEPS_IN, STAMP, FT>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, wave, lane, st + 4);
     __syncthreads();
     if constexpr (STAMP) st[7] = stamp_now();
     wp += l0;
     for (int b = 0; b < A.blocks; b++) {
         const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, wave, lane,
+        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP, FT>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, wave, lane,
                                                   st + 8 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
         wp += lf;
-        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, wave, lane,
+        conv_layer<DT, NB, G::KSTEPS_FULL, STAMP, FT>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, wave, lane,
                                                   st + 12 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
@@ -1097,6 +1101,7 @@ static int net_pack(azh_net *net, int dt)
     if (net->bufs[dt].conv_w)
         return 0;
     const int B = net->blocks;
+    const int F = net->filters, OCT = F / 32;  // run-time width (the 128-filter constants are shadowed on purpose)
     const float *p = net->conv_flat.data();
     const int kstep = dt == AZH_DTYPE_F32 ? 2 : 16;
     const int ks_in = dt == AZH_DTYPE_F32 ? 2 : 1;
@@ -1136,6 +1141,8 @@ static int net_pack(azh_net *net, int dt)
         pack_conv<uint16_t>(head.data(), nullptr, F, 1, ks_full, kstep, 1, 32, dt, hw);
         if (upload(cw.data(), cw.size() * 2, &net->bufs[dt].conv_w)) return -1;
         if (upload(hw.data(), hw.size() * 2, &net->bufs[dt].head_w)) return -1;
+        if (F != 128)
+            return 0;  // variant 2 (the tuned 16x16x32 tower) is built for 128 filters
         // variant 2
         std::vector<uint16_t> cw2, hw2;
         pack_conv16(p, sc, 4, 9, 1, 8, F, dt, cw2);
@@ -1154,8 +1161,9 @@ extern "C" int azh_net_create(int blocks, int filters, const float *conv_flat, c
 {
     if (!out || !conv_flat || !bn_flat)
         return azh_fail(-1, "azh_net_create: null argument");
-    if (filters != F)
-        return azh_fail(-2, "azh_net_create: this build supports filters == 128 (model.py:16), got %d", filters);
+    if (filters != 64 && filters != 128 && filters != 256)
+        return azh_fail(-2, "azh_net_create: towers are built for 64, 128 (model.py:16) and 256 filters, got %d", filters);
+    const int F = filters;
     if (blocks < 0 || blocks > 64)
         return azh_fail(-2, "azh_net_create: bad block count %d", blocks);
     if (azh_require_device())
@@ -1209,23 +1217,24 @@ static int current_device()
     return dev;
 }
 
-template <int DT, int NB, int WPS, bool STAMP = false>
+template <int DT, int NB, int WPS, bool STAMP = false, int FT = F>
 static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
 {
-    typedef Geo<DT, NB> G;
+    typedef Geo<DT, NB, FT> G;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "tower image does not fit one CU's LDS");
     static bool attr_set[MAX_DEVICES] = {};  // the attribute is per device: a process may drive several GPUs
     const int dev = current_device();
     if (dev < 0)
         return azh_fail(-4, "launch_tower: hipGetDevice failed");
     if (!attr_set[dev]) {
-        AZH_HIP(hipFuncSetAttribute((const void *)k_tower<DT, NB, WPS, STAMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AZH_HIP(hipFuncSetAttribute((const void *)k_tower<DT, NB, WPS, STAMP, FT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     G::LDS_BYTES));
         attr_set[dev] = true;
     }
     const int grid = (max_n + G::BOARDS - 1) / G::BOARDS;
     if (grid <= 0)
         return 0;
-    hipLaunchKernelGGL((k_tower<DT, NB, WPS, STAMP>), dim3(grid), dim3(NTHREADS), G::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL((k_tower<DT, NB, WPS, STAMP, FT>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES, stream, args);
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -1364,6 +1373,24 @@ static int net_launch(azh_net *net, int dtype, const unsigned long long *d_board
     a.sym = sym;
     if (sym)
         max_n *= 8;  // grid size: virtual boards
+    if (net->filters != 128) {
+        // Other widths (the reference's FILTERS is a class attribute, uai_interface.py:92-93 patches it): the 32x32 tower
+        // templated on the width — one wave per 32 output channels, 3 boards per workgroup (1 for f32 at 256 filters: LDS).
+        if (d_stamps)
+            return azh_fail(-2, "stamps are built for the 128-filter bf16 tower only");
+        if (net->filters == 64) {
+            switch (dtype) {
+            case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 3, 1, false, 64>(a, max_n, stream);
+            case AZH_DTYPE_BF16: return launch_tower<AZH_DTYPE_BF16, 3, 1, false, 64>(a, max_n, stream);
+            default: return launch_tower<AZH_DTYPE_F16, 3, 1, false, 64>(a, max_n, stream);
+            }
+        }
+        switch (dtype) {
+        case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 1, 2, false, 256>(a, max_n, stream);
+        case AZH_DTYPE_BF16: return launch_tower<AZH_DTYPE_BF16, 3, 2, false, 256>(a, max_n, stream);
+        default: return launch_tower<AZH_DTYPE_F16, 3, 2, false, 256>(a, max_n, stream);
+        }
+    }
     const bool six = tower_boards() == 6;
     if (tower_variant() == 2 && dtype != AZH_DTYPE_F32) {
         if (d_stamps)
@@ -1496,6 +1523,8 @@ extern "C" int azh_net_stamps(azh_net *net, int n, int wgs, uint64_t *out)
 {
     if (!net || n <= 0 || wgs <= 0 || !out)
         return azh_fail(-1, "azh_net_stamps: bad argument");
+    if (net->filters != 128)
+        return azh_fail(-2, "azh_net_stamps: built for the 128-filter bf16 tower only");
     const int grid_max = (n + 2) / 3;
     std::vector<unsigned long long> boards((size_t)n * 2);
     unsigned long long x = 0x9E3779B97F4A7C15ULL;

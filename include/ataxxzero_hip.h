@@ -90,7 +90,8 @@ typedef struct azh_net azh_net;
  * (1,1,F,1), fc_w (49,1), fc_b (1,).  bn_flat: the 2*(2*blocks+1) arrays of the
  * second list, (moving_mean, moving_variance) per batch-norm in creation order.
  * gamma = 1, beta = 0 as after model.load_model;
- * bn_eps is TensorFlow's default 1e-3. */
+ * bn_eps is TensorFlow's default 1e-3.  filters: 128 (model.py:16; the tuned towers), 64 or 256 (model.Network.FILTERS
+ * is a class attribute that uai_interface.py:92-93 patches: these run on the width-templated 32x32 tower). */
 int azh_net_create(int blocks, int filters, const float *conv_flat, const float *bn_flat,
                    float bn_eps, azh_net **out);
 void azh_net_destroy(azh_net *net);

@@ -348,9 +348,9 @@ def test_uid_ordered_emission_is_an_unbiased_prefix():
     """azh_engine_set_emit_order(1): games come out in the order they were STARTED.  What has been handed out at any
     moment is exactly the finished games among the uids below the smallest uid still in play — short and long games
     alike, dropped games (cut at max_plies) leaving no hole that blocks the queue."""
-    oe, ge = make_pair(games=48, visits=6, max_plies=70, seed=17)
+    oe, ge = make_pair(games=48, visits=6, max_plies=170, seed=17)   # the cut drops the longer half of the games
     ge.set_emit_order(True)
-    o_games, g_lines = run_lockstep(oe, ge, 2600, check_every=400)
+    o_games, g_lines = run_lockstep(oe, ge, 7000, check_every=1000)
     frontier = min(oe.game_state(g).uid for g in range(48))      # smallest uid not yet finished or dropped
     finished = sorted(o_games, key=lambda r: r["uid"])
     want = [r["entry"] for r in finished if r["uid"] < frontier]

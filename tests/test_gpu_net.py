@@ -41,6 +41,39 @@ def test_f32_tower_within_1e5_of_float64_restatement(blocks, n, perturb):
     assert np.abs(ref_p).max() > 1e-3  # the comparison is not vacuous
 
 
+@pytest.mark.parametrize("filters,blocks,n", [(64, 3, 29), (256, 2, 10), (256, 4, 7)])
+def test_other_filter_counts(filters, blocks, n):
+    """model.Network.FILTERS is a class attribute the reference patches (uai_interface.py:92-93): 64- and 256-filter nets
+    run on the width-templated 32x32 tower — f32 within 1e-5 of the float64 restatement, 16-bit paths tracking it, batch
+    position irrelevant, and the search engine plays with them."""
+    conv, bn = model.random_init(blocks, filters, seed=filters + blocks, perturb_bn=True)
+    assert conv[0].shape == (3, 3, 4, filters)
+    lb = sample_leaf_boards(n, 4, BLOCK4_MASK)
+    net = link.Net(conv, bn)
+    assert net.filters == filters
+    logits, values = net.forward(lb, BLOCK4_MASK, link.DTYPE_F32)
+    ref_p, ref_v = net_oracle.forward(conv, bn, net_oracle.features_from_leaf_boards(lb, BLOCK4_MASK))
+    assert np.abs(logits - ref_p).max() <= 1e-5, np.abs(logits - ref_p).max()
+    assert np.abs(values - ref_v).max() <= 1e-5 and np.abs(ref_p).max() > 1e-3
+    scale = float(np.abs(ref_p).max())
+    for dtype, rel in ((link.DTYPE_BF16, 4e-2), (link.DTYPE_F16, 5e-3)):
+        p, v = net.forward(lb, BLOCK4_MASK, dtype)
+        assert np.abs(p - logits).max() <= rel * scale and np.abs(v - values).max() <= rel
+    part_p, part_v = net.forward(lb[:4], BLOCK4_MASK, link.DTYPE_F32)
+    assert (part_p == logits[:4]).all() and (part_v == values[:4]).all()
+    sp, sv = net.forward_sym(lb[:3], BLOCK4_MASK, link.DTYPE_F32)
+    rp, rv = net_oracle.forward_sym(conv, bn, net_oracle.features_from_leaf_boards(lb[:3], BLOCK4_MASK))
+    assert np.abs(sp - rp).max() <= 1e-5 and np.abs(sv - rv).max() <= 1e-5
+    ocfg = orc.make_config(40, 10, seed=2)
+    ge = link.Engine(link.Config(**{k: getattr(ocfg, k) for k, _ in orc.Config._fields_}))
+    ge.run(net, 120, link.DTYPE_BF16)
+    ge.sync()
+    st = ge.stats()
+    assert st["plies"] > 40 * 5 and st["edge_overflow"] == 0
+    with pytest.raises(link.AzhError):
+        link.Net(*model.random_init(1, 96, seed=1))   # only 64 / 128 / 256 are built
+
+
 def test_first_boards_of_partial_tiles_and_empty_batch():
     conv, bn = model.random_init(1, 128, seed=4, perturb_bn=True)
     net = link.Net(conv, bn)
