@@ -116,3 +116,28 @@ def test_uai_ringmaster_cli(tmp_path):
     assert text.count('[Event "?"]') == 40 and text.count("[FinalScore ") == 40
     assert re.search(r'\[Result "(1-0|0-1|1/2-1/2)"\]', text)
     assert 'model-001.npy' in text and 'model-002.npy' in text
+
+
+def test_config5_size_match_is_deterministic():
+    """BASELINE configs[4]: a 1000-game arena between two 12x128 nets with deterministic seeds — played twice, the fixed
+    cohort (uids 0..999, every pairing both ways) must come out identical game for game, and scoring a fixed cohort
+    instead of the first finishers counts every game once."""
+    nets = [model.random_init(12, 128, seed=s) for s in (1, 2)]
+
+    def play():
+        m = arena.Match(nets[0], nets[1], visits=24, games=1000, dtype="bf16", seed=20260101, max_plies=120)
+        done = {}
+        for _ in range(4000):
+            m.run(50)
+            for g in m.drain():
+                if g["uid"] < 1000:
+                    done[g["uid"]] = (tuple(g["moves"]), g["result"], g["white"])
+            if len(done) == 1000:
+                break
+        m.close()
+        return done
+
+    a, b = play(), play()
+    assert len(a) == 1000 and a == b
+    assert sum(1 for v in a.values() if v[2] == "a") == 500   # each net has x in half of the cohort
+    assert len({v[0] for v in a.values()}) > 900               # the games are not copies of one another
