@@ -50,8 +50,8 @@ struct EngineParams {
     int start_turn;
     u32 flags;
     int select_budget;  // tree levels per select launch and game (0 = unlimited), azh_config.select_budget
-    int *opening_until;  // azh_engine_set_opening_sims: slot g plays `opening_visits` sims/move until one of its games
-    int opening_visits;  // reaches ply opening_until[g]; the entry is then cleared (null = off)
+    int *no_emit;        // [G] 1 = the slot's current game was started from a loaded position (azh_engine_set_positions):
+                         // it is played and counted, but its record would lack the plies before the start, so it is not written
     azh_game_state *gs;
     int *force;
     int *adv_list;   // games whose move is due (phase 2), appended by mark_game, consumed by k_advance_list
@@ -127,14 +127,11 @@ __device__ inline void add_stat(const EngineParams &P, int g, int k, u64 v)
 
 // Fresh tree at the start position in arena 0 (generate_game :510-512,
 // MCTS::init_from_scratch :380-383).  Wave-cooperative; s_moves is LDS scratch.
-__device__ inline void init_game(const EngineParams &P, int g, u32 uid, azh_game_state &s, u16 *s_moves)
+__device__ inline void init_game_at(const EngineParams &P, int g, u32 uid, azh_game_state &s, u16 *s_moves, Board b, int ply,
+                                    int loaded)
 {
     const int lane = lane_id();
     Arena A = arena_of(P, 0, g);
-    Board b;
-    b.x = P.start_x;
-    b.o = P.start_o;
-    b.turn = P.start_turn;
     int res;
     const int M = wave_movegen(b, P.blockers, s_moves, &res);
     __syncthreads();
@@ -147,18 +144,41 @@ __device__ inline void init_game(const EngineParams &P, int g, u32 uid, azh_game
         A.nb[0] = make_ulonglong2(pack_word0(b), b.o);
         A.ni[0] = make_uint4(0u, (u32)M | ((u32)res << 16), 0u, 0u);
         P.force[g] = 0;
+        P.no_emit[g] = loaded;
     }
     __syncthreads();
     s.phase = 0;
     s.arena = 0;
     s.n_nodes = 1;
     s.n_edges = M;
-    s.ply = 0;
+    s.ply = ply;
     s.root_visits = 0;
     s.leaf_kind = AZH_LEAF_NONE;
     s.leaf_node = 0;
     s.path_len = 0;
     s.uid = uid;
+}
+
+// Fresh game at the configured start position.
+__device__ inline void init_game(const EngineParams &P, int g, u32 uid, azh_game_state &s, u16 *s_moves)
+{
+    Board b;
+    b.x = P.start_x;
+    b.o = P.start_o;
+    b.turn = P.start_turn;
+    init_game_at(P, g, uid, s, s_moves, b, 0, 0);
+}
+
+// azh_engine_set_positions: every slot restarts at a given position and ply (fresh tree, uid = slot)
+__global__ __launch_bounds__(WAVE) void k_init_positions(EngineParams P, const ulonglong2 *boards, const int *plies)
+{
+    __shared__ u16 s_moves[MAX_MOVES];
+    const int g = blockIdx.x;
+    azh_game_state s;
+    const ulonglong2 w = boards[g];
+    init_game_at(P, g, (u32)g, s, s_moves, unpack_board(w.x, w.y), plies[g], 1);
+    if (threadIdx.x == 0)
+        P.gs[g] = s;
 }
 
 __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
@@ -852,8 +872,14 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
             out[4] = 0; out[5] = 8; out[6] = 0; out[7] = 1;  // word 7: dropped
         }
     };
+    const bool loaded = P.no_emit[g] != 0;  // started from a loaded position: counted, not written (its first plies are missing)
     if (no_sample) {
         st_dropped = 1;
+        drop_marker();
+        init_game(P, g, s.uid + (u32)P.G, s, s_moves);
+    } else if (loaded && (result != 0 || cut)) {
+        st_games = result != 0 ? 1 : 0;
+        st_dropped = result != 0 ? 0 : 1;
         drop_marker();
         init_game(P, g, s.uid + (u32)P.G, s, s_moves);
     } else if (result != 0 || (cut && (P.flags & AZH_FLAG_KEEP_UNFINISHED))) {
@@ -937,17 +963,7 @@ __device__ inline void mark_game(const EngineParams &P, int g)
     if (lane_id() != 0)
         return;
     const azh_game_state s = P.gs[g];
-    int need = P.visits;
-    if (P.opening_until) {
-        const int until = P.opening_until[g];
-        if (until > 0) {
-            if (s.ply < until)
-                need = P.opening_visits;
-            else
-                P.opening_until[g] = 0;  // the slot has reached its age: full-price searches from here on
-        }
-    }
-    if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= need || P.force[g] != 0)) {
+    if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= P.visits || P.force[g] != 0)) {
         P.gs[g].phase = 2;
         P.adv_list[atomicAdd(P.adv_count, 1)] = g;
     }
@@ -1030,7 +1046,6 @@ struct azh_engine {
     float *d_feat = nullptr;
     float *d_sym_logits = nullptr, *d_sym_values = nullptr;  // AZH_FLAG_SYMMETRY_AVG scratch
     u64 *d_stat_out = nullptr;
-    int *d_opening = nullptr;
     // finished games formatted but not yet handed out
     std::vector<std::string> pending;
     size_t pending_pos = 0;
@@ -1103,6 +1118,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     int rc = 0;
     rc |= dev_alloc(e, &P.gs, G);
     rc |= dev_alloc(e, &P.force, G);
+    rc |= dev_alloc(e, &P.no_emit, G);
     rc |= dev_alloc(e, &P.adv_list, G);
     rc |= dev_alloc(e, &P.adv_count, 1);
     rc |= dev_alloc(e, &P.path, G * P.path_cap);
@@ -1410,25 +1426,37 @@ extern "C" int azh_engine_set_emit_order(azh_engine *e, int by_uid)
     return 0;
 }
 
-// Cheap openings: slot g needs only `visits_low` root visits per move until one of its games reaches ply until_ply[g]
-// (games that end earlier are followed by another cheap game); from that ply on, and in every later game of the slot,
-// the configured sims/move apply.  A measurement set-up hook: bench.py puts every slot at the age a generator that has
-// been running for a long time would show, without paying full-price searches for the plies before it; until_ply =
-// NULL switches it off.
-extern "C" int azh_engine_set_opening_sims(azh_engine *e, const int32_t *until_ply, int visits_low)
+// Every slot restarts at a given position: boards [G][2] packed (x | turn << 63, o), plies [G] (the ply the position is at;
+// < max_plies).  Fresh trees, uids = slot numbers.  Games started this way are played and counted like any other, but
+// their records would lack the plies before the start, so they are not written (the slot's NEXT game is a normal one).
+// A measurement set-up hook: bench.py loads the positions a long-running generator was found at
+// (profiles/round2_steady_state_positions.npz) instead of waiting a game generation for the steady state to form.
+extern "C" int azh_engine_set_positions(azh_engine *e, const uint64_t *boards, const int32_t *plies)
 {
-    if (!e || (until_ply && (visits_low < 1 || visits_low > e->cfg.visits)))
-        return azh_fail(-1, "azh_engine_set_opening_sims: need 1 <= visits_low <= %d", e ? e->cfg.visits : 0);
+    if (!e || !boards || !plies)
+        return azh_fail(-1, "azh_engine_set_positions: null argument");
     AZH_HIP(hipStreamSynchronize(e->stream));
-    if (!until_ply) {
-        e->P.opening_until = nullptr;
-        return 0;
+    AZH_HIP(hipStreamSynchronize(e->stream2));
+    const size_t G = (size_t)e->P.G;
+    for (size_t g = 0; g < G; g++) {
+        const uint64_t x = boards[2 * g] & ~TURN_BIT, o = boards[2 * g + 1];
+        if (plies[g] < 0 || plies[g] >= e->P.max_plies || (x & o) || ((x | o) & (e->P.blockers | ~BOARD_MASK)) || !x || !o)
+            return azh_fail(-2, "azh_engine_set_positions: slot %zu: bad position or ply %d", g, plies[g]);
     }
-    if (!e->d_opening && dev_alloc(e, &e->d_opening, (size_t)e->P.G))
-        return -1;
-    AZH_HIP(hipMemcpy(e->d_opening, until_ply, (size_t)e->P.G * 4, hipMemcpyHostToDevice));
-    e->P.opening_until = e->d_opening;
-    e->P.opening_visits = visits_low;
+    ulonglong2 *d_b = nullptr;
+    int *d_p = nullptr;
+    AZH_HIP(hipMalloc((void **)&d_b, G * 16));
+    AZH_HIP(hipMalloc((void **)&d_p, G * 4));
+    hipError_t rc = hipMemcpy(d_b, boards, G * 16, hipMemcpyHostToDevice);
+    if (rc == hipSuccess) rc = hipMemcpy(d_p, plies, G * 4, hipMemcpyHostToDevice);
+    if (rc == hipSuccess) rc = hipMemsetAsync(e->P.adv_count, 0, sizeof(int), e->stream);
+    if (rc == hipSuccess) {
+        hipLaunchKernelGGL(k_init_positions, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P, (const ulonglong2 *)d_b, (const int *)d_p);
+        rc = hipStreamSynchronize(e->stream);
+    }
+    (void)hipFree(d_b);
+    (void)hipFree(d_p);
+    AZH_HIP(rc);
     return 0;
 }
 

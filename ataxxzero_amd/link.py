@@ -99,7 +99,7 @@ SIGNATURES = {
     "azh_engine_timing": (ctypes.c_int, [_vp, _P(Timing)]),
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
     "azh_engine_set_emit_order": (ctypes.c_int, [_vp, ctypes.c_int]),
-    "azh_engine_set_opening_sims": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    "azh_engine_set_positions": (ctypes.c_int, [_vp, _vp, _vp]),
     # the reference's ABI, link.py:8-32
     "launch_threads": (None, [ctypes.c_char_p, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     "get_workload": (ctypes.c_int, []),
@@ -348,10 +348,11 @@ class Engine:
     def set_visits(self, visits):
         check(load().azh_engine_set_visits(self.h, visits))
 
-    def set_opening_sims(self, until_ply, visits_low):
-        """First game of slot g: `visits_low` sims/move while ply < until_ply[g] (None switches the hook off)."""
-        arr = None if until_ply is None else np.ascontiguousarray(until_ply, dtype=np.int32).reshape(self.G)
-        check(load().azh_engine_set_opening_sims(self.h, _ptr(arr), int(visits_low)))
+    def set_positions(self, boards, plies):
+        """Every slot restarts at boards[g] (packed x | turn << 63, o) / plies[g] with a fresh tree (counted, not written)."""
+        boards = np.ascontiguousarray(boards, dtype=np.uint64).reshape(self.G, 2)
+        plies = np.ascontiguousarray(plies, dtype=np.int32).reshape(self.G)
+        check(load().azh_engine_set_positions(self.h, _ptr(boards), _ptr(plies)))
 
     def set_emit_order(self, by_uid):
         """True: finished games are handed out in uid order (unbiased prefixes); False: as they finish."""

@@ -102,11 +102,20 @@ class SelfPlay:
         for e in self.engines:
             e.set_visits(visits)
 
-    def set_opening_sims(self, until_ply, visits_low):
+    def set_positions(self, boards, plies):
         lo = 0
         for e in self.engines:
-            e.set_opening_sims(None if until_ply is None else until_ply[lo:lo + e.G], visits_low)
+            e.set_positions(boards[lo:lo + e.G], plies[lo:lo + e.G])
             lo += e.G
+
+    def positions(self):
+        """(root boards packed (G,2) u64, plies (G,)) of all slots: what set_positions takes."""
+        boards, plies = [], []
+        for e in self.engines:
+            for g in range(e.G):
+                boards.append(e.tree(g)[0][0])
+                plies.append(e.game_state(g).ply)
+        return np.asarray(boards, dtype=np.uint64), np.asarray(plies, dtype=np.int32)
 
     def set_emit_order(self, by_uid):
         for e in self.engines:

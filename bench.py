@@ -108,12 +108,18 @@ def cpu_baseline(net, visits, dtype, seconds):
 
 def measure(sp, args, steps, warmup, group=None):
     """`warmup` untimed steps, then EXACTLY `steps` timed steps between barriers + device syncs."""
+    per_step = []
+    seen = [sp.stats()["games"]]
+
     def run_steps(n):
-        finished = 0
+        written = 0
         for _ in range(n):
             sp.run(args.iters_per_step)
-            finished += len(sp.drain())   # sync + hand the finished games to the host, as the CLI does
-        return finished
+            written += len(sp.drain())    # sync + hand the finished games to the host, as the CLI does
+            now = sp.stats()["games"]     # games finished so far (device counter)
+            per_step.append(now - seen[0])
+            seen[0] = now
+        return written
 
     run_steps(warmup)
     sp.sync()
@@ -128,39 +134,36 @@ def measure(sp, args, steps, warmup, group=None):
     if group is not None:
         group.barrier()
     st1 = sp.stats()
+    measure.finished_per_step = per_step[warmup:]
     return {k: st1[k] - st0[k] for k in st1}, finished, t1 - t0, sp.timing()
 
 
-def stationary_ages(n, seed):
-    """Ages (plies already played) of the game slots of a generator that has been running for a long time: for a
-    renewal process the age distribution is P(age = a) ~ P(L > a), with L the game length.  L comes from one complete
-    generation of real games at this workload (profiles/round2_game_lengths.json, tools/length_histogram.py: 4096
-    games, mean 152.4 plies)."""
-    import numpy as np
-    with open(os.path.join(ROOT, "profiles", "round2_game_lengths.json")) as f:
-        hist = np.asarray(json.load(f)["histogram_plies"], dtype=np.float64)
-    survival = hist[::-1].cumsum()[::-1] - hist          # survival[a] = #games longer than a plies
-    p = survival / survival.sum()
-    return np.random.default_rng(seed).choice(len(p), size=n, p=p).astype(np.int32)
+SNAPSHOT = os.path.join("profiles", "round2_steady_state_positions.npz")
 
 
 def spread(sp, args, seed):
     """Untimed set-up: a fresh start has every game at ply 0 with an empty tree — nothing like the state the generator
-    works in.  Every slot is given an age drawn from the stationary age distribution (stationary_ages) and plays 4-sim
-    moves until it is that old (azh_engine_set_opening_sims); then --phase-fill iterations at full sims/move regrow
-    the trees.  `--phase-mix 0` skips all of it."""
-    if args.phase_mix <= 0:
+    works in, and the steady state takes several game generations (one is about 70 s) to form.  The slots are therefore
+    LOADED with steady-state positions built from one complete generation of real games of this very workload
+    (profiles/round2_steady_state_positions.npz, tools/steady_state_positions.py; sampled with replacement when the
+    batch is not 4096 games), azh_engine_set_positions; --phase-fill iterations at full sims/move then grow the trees.
+    Games that start from a loaded position are played and counted, not written.  `--phase-fill 0` starts cold."""
+    if args.phase_fill <= 0:
         return None
-    ages = stationary_ages(sp.games, seed)
-    sp.set_opening_sims(ages, min(4, args.visits))
-    for budget in (args.phase_mix, args.phase_fill):
-        done = 0
-        while done < budget:
-            sp.run(min(250, budget - done))
-            sp.drain()
-            done += 250
-    sp.set_opening_sims(None, 1)
-    return {"mean_age_plies": float(ages.mean()), "max_age_plies": int(ages.max())}
+    import numpy as np
+    snap = np.load(os.path.join(ROOT, SNAPSHOT))
+    boards, plies = snap["boards"], snap["plies"]
+    if sp.games == len(plies):
+        pick = np.arange(len(plies))
+    else:
+        pick = np.random.default_rng(seed).integers(0, len(plies), size=sp.games)
+    sp.set_positions(boards[pick], plies[pick])
+    done = 0
+    while done < args.phase_fill:
+        sp.run(min(250, args.phase_fill - done))
+        sp.drain()
+        done += 250
+    return {"mean_ply": float(plies[pick].mean()), "source": SNAPSHOT}
 
 
 def target_leg(conv, bn, args, games=16384, steps=2, warmup=1):
@@ -175,7 +178,7 @@ def target_leg(conv, bn, args, games=16384, steps=2, warmup=1):
         it = max(tm["iterations"], 1)
         iters = steps * args.iters_per_step
         tf = d["nn_evals"] / float(iters) * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] / it * 1e-3) / 1e12
-        return {"games": games, "node_evals_per_s": d["steps"] / dt, "games_per_s": finished / dt,
+        return {"games": games, "node_evals_per_s": d["steps"] / dt, "games_per_s": d["games"] / dt,
                 "ms_per_iteration": 1e3 * dt / iters, "steps": steps,
                 "tower_ms_per_launch": tm["net_ms"] / it, "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[args.dtype],
                 "tree_ms_per_iteration": (tm["select_ms"] + tm["backup_ms"]) / it}
@@ -218,12 +221,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--streams", type=int, default=1, help="half-batches in flight per GPU (the reference's double buffer)")
-    ap.add_argument("--phase-mix", type=int, default=3000,
-                    help="untimed set-up iterations in which every slot plays 4-sim moves up to an age drawn from the "
-                         "stationary age distribution of the generator (profiles/round2_game_lengths.json), followed by "
-                         "--phase-fill iterations at full sims/move that regrow the trees; then the --warmup steps.  "
-                         "0 = start cold (every game at ply 0)")
-    ap.add_argument("--phase-fill", type=int, default=500)
+    ap.add_argument("--phase-fill", type=int, default=1000,
+                    help="untimed set-up: the slots are loaded with steady-state positions (profiles/"
+                         "round2_steady_state_positions.npz) and the trees are grown for this many iterations at full "
+                         "sims/move before the --warmup steps; 0 = cold start (every game at ply 0)")
     ap.add_argument("--select-budget", type=int, default=48,
                     help="tree levels per select launch and game (azh_config.select_budget; 0 = unlimited): deeper "
                          "descents park and resume next iteration, so a launch does not last as long as the deepest "
@@ -270,7 +271,8 @@ def main():
     steps_total, t_max, rate = distrib.aggregate(group, d["steps"], dt)
     evals_total = group.reduce(d["nn_evals"], "sum")
     plies_total = group.reduce(d["plies"], "sum")
-    games_total = group.reduce(finished, "sum")
+    games_total = group.reduce(d["games"], "sum")     # finished games (result 1 or 2), device counter
+    written_total = group.reduce(finished, "sum")      # of which written out (games from loaded positions are not)
 
     if group.rank == 0:
         flops = model.flops_per_eval(args.blocks, 128)
@@ -296,15 +298,17 @@ def main():
                                % args.iters_per_step,
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
                        "select_budget": args.select_budget,
-                       "setup": ("slots aged to the generator's stationary age distribution (mean %.0f plies) by %d untimed "
-                                 "iterations of 4-sim moves + %d at full sims, then the warm-up"
-                                 % (ages["mean_age_plies"], args.phase_mix, args.phase_fill)) if ages else "cold start",
+                       "setup": ("slots loaded with the positions of a generator 300 s into this workload (%s, mean ply %.0f), "
+                                 "trees grown for %d untimed iterations, then the warm-up"
+                                 % (ages["source"], ages["mean_ply"], args.phase_fill)) if ages else "cold start",
                        "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},
             "ms_per_iteration": 1e3 * t_max / iters,
             "nn_evals_per_s": evals_total / t_max, "plies_per_s": plies_total / t_max,
-            "games_per_s": games_total / t_max,    # finished games (result 1 or 2) handed to the host in the timed region
+            "games_per_s": games_total / t_max,    # games finished (result 1 or 2) in the timed region, counted on the device
+            "game_lines_written_in_timed_region": written_total,
             "games_finished_in_timed_region": games_total,
+            "games_finished_per_step_rank0": measure.finished_per_step,   # flat = the set-up reached steady state
             "mean_plies_per_finished_game": plies_total / games_total if games_total else None,
             "roofline": {"bound": "mfma", "kernel": "%s<%s>" % ("k_tower" if args.dtype == "f32" or os.environ.get("AZH_TOWER") == "1" else "k_tower2", args.dtype), "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,

@@ -213,11 +213,11 @@ int azh_engine_sync(azh_engine *e);
  * value the engine was created with */
 int azh_engine_set_visits(azh_engine *e, int visits);
 
-/* Measurement set-up hook: slot g needs only visits_low root visits per move until one of its games reaches ply
- * until_ply[g] ([games] host array; NULL switches the hook off; a game that ends earlier is followed by another cheap
- * one); from that ply on the configured sims/move apply.  bench.py uses it to put every slot at the age a long-running
- * generator would find it at. */
-int azh_engine_set_opening_sims(azh_engine *e, const int32_t *until_ply, int visits_low);
+/* Measurement set-up hook: every slot restarts at a given position — boards [games][2] packed (x | turn << 63, o),
+ * plies [games] — with a fresh tree.  Such games are played and counted (AZH_STAT_GAMES / _DROPPED) but not written: their
+ * records would lack the plies before the start.  bench.py loads the positions a long-running generator was found at
+ * instead of waiting a game generation (about 70 s at 400 sims/move) for the steady state to form. */
+int azh_engine_set_positions(azh_engine *e, const uint64_t *boards, const int32_t *plies);
 
 int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out);
 /* arena dump: boards [n_nodes][2] u64, info [n_nodes][4] u32

@@ -41,8 +41,7 @@ struct orc_engine {
     uint64_t *stats;
     blob *done_head, *done_tail;
     int done_count;
-    int32_t *opening_until;  /* orc_engine_set_opening_sims */
-    int opening_visits;
+    int32_t *no_emit;  /* [G] the slot's current game was started by orc_engine_set_positions: counted, not written */
 };
 
 static inline uint64_t *NB(const orc_engine *e, int a, int g) { return e->node_board + ((size_t)(a * e->G + g) * e->node_cap) * 2; }
@@ -136,6 +135,7 @@ static void init_game(orc_engine *e, int g, uint32_t uid)
     s->uid = uid;
     s->phase = ORC_PHASE_ROOT_EVAL;
     e->force[g] = 0;
+    e->no_emit[g] = 0;
     orc_pos p;
     p.pieces[0] = e->cfg.start_x;
     p.pieces[1] = e->cfg.start_o;
@@ -157,6 +157,7 @@ orc_engine *orc_engine_create(const orc_config *cfg)
     size_t G = (size_t)e->G;
     e->gs = (orc_game_state *)calloc(G, sizeof(orc_game_state));
     e->force = (int32_t *)calloc(G, sizeof(int32_t));
+    e->no_emit = (int32_t *)calloc(G, sizeof(int32_t));
     e->path = (int32_t *)calloc(G * e->path_cap, sizeof(int32_t));
     e->node_board = (uint64_t *)calloc(2 * G * e->node_cap * 2, sizeof(uint64_t));
     e->node_info = (uint32_t *)calloc(2 * G * e->node_cap * 4, sizeof(uint32_t));
@@ -174,21 +175,29 @@ void orc_engine_destroy(orc_engine *e)
     if (!e) return;
     while (e->done_head) { blob *n = e->done_head->next; free(e->done_head); e->done_head = n; }
     free(e->gs); free(e->force); free(e->path); free(e->node_board); free(e->node_info);
-    free(e->edge); free(e->edge_move); free(e->rec); free(e->stats); free(e->opening_until); free(e);
+    free(e->edge); free(e->edge_move); free(e->rec); free(e->stats); free(e->no_emit); free(e);
 }
 
 int orc_engine_node_cap(const orc_engine *e) { return e->node_cap; }
 void orc_engine_set_visits(orc_engine *e, int visits) { e->cfg.visits = visits; }
-void orc_engine_set_opening_sims(orc_engine *e, const int32_t *until_ply, int visits_low)
+/* mirror of azh_engine_set_positions: every slot restarts at boards[g] (x | turn << 63, o) / plies[g], fresh tree, uid = g */
+void orc_engine_set_positions(orc_engine *e, const uint64_t *boards, const int32_t *plies)
 {
-    free(e->opening_until);
-    e->opening_until = NULL;
-    if (until_ply) {
-        e->opening_until = (int32_t *)malloc(sizeof(int32_t) * (size_t)e->G);
-        memcpy(e->opening_until, until_ply, sizeof(int32_t) * (size_t)e->G);
-        e->opening_visits = visits_low;
+    for (int g = 0; g < e->G; g++) {
+        orc_game_state *s = &e->gs[g];
+        memset(s, 0, sizeof(*s));
+        s->uid = (uint32_t)g;
+        s->phase = ORC_PHASE_ROOT_EVAL;
+        s->ply = plies[g];
+        e->force[g] = 0;
+        e->no_emit[g] = 1;
+        orc_pos p;
+        unpack(e, boards + 2 * (size_t)g, &p);
+        make_node(e, g, 0, 0, &p, NULL);
+        s->n_nodes = 1;
     }
 }
+
 int orc_engine_edge_cap(const orc_engine *e) { return e->edge_cap; }
 
 /* cpp/self_play_client.cpp:386-447: descend by PUCT, expand one node. */
@@ -614,7 +623,12 @@ static void advance_game(orc_engine *e, int g)
     s->ply += 1;
     e->force[g] = 0;
     int result = (int)(ni2[1] >> 16);
-    if (result != 0 && (e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE) && random_ply_of(e, s->uid) + 1 >= s->ply) {
+    if (e->no_emit[g] && (result != 0 || s->ply >= e->cfg.max_plies) &&
+        !((e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE) && result != 0 && random_ply_of(e, s->uid) + 1 >= s->ply)) {
+        /* started from a loaded position: played and counted, not written */
+        if (result != 0) st[ORC_STAT_GAMES]++; else st[ORC_STAT_DROPPED]++;
+        init_game(e, g, s->uid + (uint32_t)e->G);
+    } else if (result != 0 && (e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE) && random_ply_of(e, s->uid) + 1 >= s->ply) {
         /* "Skipping game with no board state just after the uniformly random move" (:632-637) */
         st[ORC_STAT_DROPPED]++;
         init_game(e, g, s->uid + (uint32_t)e->G);
@@ -654,19 +668,11 @@ void orc_engine_backup(orc_engine *e, const float *logits, const float *values)
         default:
             break;
         }
-        /* cheap openings (orc_engine_set_opening_sims): looked at for every game in every iteration, as the engine does */
-        int need = e->cfg.visits;
-        if (e->opening_until && e->opening_until[g] > 0) {
-            if (s->ply < e->opening_until[g])
-                need = e->opening_visits;
-            else
-                e->opening_until[g] = 0; /* the slot has reached its age */
-        }
         if (s->leaf_kind == ORC_LEAF_DESCENT)
             continue; /* parked descent: nothing to back up, and the tree must stay as it is */
         s->leaf_kind = ORC_LEAF_NONE;
         /* while (root.all_edge_visits < global_visits) step(); (:522-525): the move is due */
-        if (s->phase == ORC_PHASE_SEARCH && (s->root_visits >= need || e->force[g]))
+        if (s->phase == ORC_PHASE_SEARCH && (s->root_visits >= e->cfg.visits || e->force[g]))
             s->phase = ORC_PHASE_ADVANCING;
     }
 }

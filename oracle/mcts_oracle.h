@@ -84,8 +84,9 @@ int orc_engine_edge_cap(const orc_engine *e);
 /* root-visit threshold for the coming moves, 1 .. the value the engine was created with (the arenas are sized for
  * that); mirror of azh_engine_set_visits */
 void orc_engine_set_visits(orc_engine *e, int visits);
-/* mirror of azh_engine_set_opening_sims: slot g needs visits_low root visits per move until a game of it reaches ply until_ply[g] */
-void orc_engine_set_opening_sims(orc_engine *e, const int32_t *until_ply, int visits_low);
+/* mirror of azh_engine_set_positions: every slot restarts at boards[g] (x | turn << 63, o) / plies[g] with a fresh tree;
+ * such games are counted, not written */
+void orc_engine_set_positions(orc_engine *e, const uint64_t *boards, const int32_t *plies);
 
 /* phase 1 of an iteration: select/expand in every game; returns #leaves needing
  * the evaluator.  need_eval[g] (optional) = 1 for those games. */

@@ -74,7 +74,7 @@ def lib():
         "orc_engine_create": (vp, [P(Config)]), "orc_engine_destroy": (None, [vp]),
         "orc_engine_node_cap": (ctypes.c_int, [vp]), "orc_engine_edge_cap": (ctypes.c_int, [vp]),
         "orc_engine_set_visits": (None, [vp, ctypes.c_int]),
-        "orc_engine_set_opening_sims": (None, [vp, vp, ctypes.c_int]),
+        "orc_engine_set_positions": (None, [vp, vp, vp]),
         "orc_engine_select": (ctypes.c_int, [vp, vp]), "orc_engine_leaf_boards": (None, [vp, vp]),
         "orc_engine_leaf_features": (None, [vp, ctypes.c_int, vp]),
         "orc_engine_backup": (None, [vp, vp, vp]),
@@ -209,9 +209,10 @@ class Engine:
     def set_visits(self, visits):
         lib().orc_engine_set_visits(self.h, visits)
 
-    def set_opening_sims(self, until_ply, visits_low):
-        arr = None if until_ply is None else np.ascontiguousarray(until_ply, dtype=np.int32)
-        lib().orc_engine_set_opening_sims(self.h, None if arr is None else arr.ctypes.data, int(visits_low))
+    def set_positions(self, boards, plies):
+        boards = np.ascontiguousarray(boards, dtype=np.uint64).reshape(self.G, 2)
+        plies = np.ascontiguousarray(plies, dtype=np.int32).reshape(self.G)
+        lib().orc_engine_set_positions(self.h, boards.ctypes.data, plies.ctypes.data)
 
     def select(self):
         need = np.zeros(self.G, dtype=np.int32)

@@ -293,7 +293,7 @@ def test_accelerated_generate_games_extension_flags(tmp_path):
 def test_bench_contract_line():
     """bench.py prints ONE JSON line with the driver's keys, the roofline and the cpu_baseline objects."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--games", "96", "--visits", "8", "--blocks", "1",
-                          "--steps", "30", "--warmup", "10", "--iters-per-step", "10", "--phase-mix", "40", "--phase-fill", "10",
+                          "--steps", "30", "--warmup", "10", "--iters-per-step", "10", "--phase-fill", "30",
                           "--cpu-seconds", "1.5", "--no-target-leg"], cwd=ROOT, capture_output=True, timeout=400)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     lines = [l for l in res.stdout.decode().splitlines() if l.strip()]
@@ -322,7 +322,7 @@ def test_bench_py_two_ranks_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(AZH_DEVICE_MOD="1", AZH_DIST_BACKEND="gloo")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--iters-per-step", "60", "--games", "256", "--visits", "16", "--blocks", "2", "--phase-mix", "120",
+                          "--iters-per-step", "60", "--games", "256", "--visits", "16", "--blocks", "2",
                           "--phase-fill", "30", "--no-cpu-baseline", "--no-target-leg"], env=env, cwd=ROOT,
                          capture_output=True, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-3000:]

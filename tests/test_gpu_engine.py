@@ -363,16 +363,28 @@ def test_uid_ordered_emission_is_an_unbiased_prefix():
     assert np.mean(first_finishers) < np.mean(prefix) + 1e-9 and np.mean(first_finishers) < np.mean(lengths_all)
 
 
-def test_cheap_openings_hook_matches_oracle():
-    # azh_engine_set_opening_sims (bench.py's set-up): slot g's first game plays 3-sim moves up to a per-slot ply
-    oe, ge = make_pair(games=24, visits=20, max_plies=200, seed=8)
-    until = (np.arange(24) * 7) % 60
-    for e in (oe, ge):
-        e.set_opening_sims(until, 3)
-    run_lockstep(oe, ge, 1500, check_every=97)
-    st = oe.stats()
-    # far more plies than 1500 iterations of 20-sim moves could make: the openings were cheap
-    assert st["plies"] > 24 * 1500 / 21 * 1.5
-    for e in (oe, ge):
-        e.set_opening_sims(None, 1)
-    run_lockstep(oe, ge, 200, check_every=50)
+def test_loaded_positions_hook_matches_oracle():
+    # azh_engine_set_positions (bench.py's steady-state set-up): every slot restarts at a mid-game position and ply; those
+    # games are played and counted but not written; the slot's next game is an ordinary one
+    oe, ge = make_pair(games=24, visits=10, max_plies=200, seed=8)
+    run_lockstep(oe, ge, 700, check_every=100)                      # let the games reach different plies first
+    boards = np.array([ge.tree(g)[0][0] for g in range(24)], dtype=np.uint64)
+    plies = np.array([ge.game_state(g).ply for g in range(24)], dtype=np.int32)
+    assert plies.max() > 20 and len(set(plies.tolist())) > 5
+    oe2, ge2 = make_pair(games=24, visits=10, max_plies=200, seed=9)
+    for e in (oe2, ge2):
+        e.set_positions(boards, plies)
+    for g in range(24):
+        assert ge2.game_state(g).ply == plies[g] and (ge2.tree(g)[0][0] == boards[g]).all()
+    o_games, g_lines = run_lockstep(oe2, ge2, 4000, check_every=250)
+    so, sg = oe2.stats(), ge2.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    # the 24 loaded games ended (finished or cut) without a line; later games of the slots are written normally
+    assert so["games"] + so["dropped"] > 24 and 0 < len(g_lines) == len(o_games) <= so["games"] + so["dropped"] - 24 + 24
+    assert len(g_lines) < so["games"] + so["dropped"]
+    for line in g_lines:
+        entry = json.loads(line)
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]   # complete games from the start position
+    with pytest.raises(link.AzhError):
+        ge2.set_positions(boards, np.full(24, 200, np.int32))       # ply beyond max_plies

@@ -14,7 +14,21 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc3 -- python3 $R/b
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc4 -- python3 $R/bench.py $ARGS > $OUT/pmc4.log 2>&1 || exit 5
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc5 -- python3 $R/bench.py $ARGS > $OUT/pmc5.log 2>&1 || exit 6
 # keep the merge small: the per-dispatch counter CSVs are large; summarise on the box
-python3 $R/tools/prof_summary.py $OUT k_tower > $OUT/summary_k_tower.txt 2>&1
+# timed-region average of the tower from the kernel trace (the stats CSV averages over set-up and warm-up too):
+# the last steps x 250 launches are the timed ones
+python3 - "$OUT" "$ARGS" > $OUT/timed_region.txt <<'PY'
+import csv, glob, os, re, sys
+f = max(glob.glob(os.path.join(sys.argv[1], "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
+m = re.search(r"--steps (\d+)", sys.argv[2])
+n = (int(m.group(1)) if m else 40) * 250
+for name in ("k_tower", "k_tree", "k_compact"):
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if name in r["Kernel_Name"]]
+    d = d[-n:]
+    print("rocprofv3 kernel trace, last %d launches (the timed region): %-10s mean %.1f us  p50 %.1f us" % (
+        len(d), name, sum(d) / len(d) / 1e3, sorted(d)[len(d) // 2] / 1e3))
+PY
+cat $OUT/timed_region.txt > $OUT/summary_k_tower.txt
+python3 $R/tools/prof_summary.py $OUT k_tower >> $OUT/summary_k_tower.txt 2>&1
 for k in k_tree k_select k_compact; do python3 $R/tools/prof_summary.py $OUT $k > $OUT/summary_$k.txt 2>&1; done
 find $OUT -name "*_counter_collection.csv" -delete
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete

@@ -25,4 +25,4 @@ for line in open("$OUT/model-001-0.json"):
 print("games", n, "mean plies", sum(pl)/max(n,1), "min/max", (min(pl), max(pl)) if pl else None, "results", res)
 PY
 ls -la $OUT/model-001-0.json; rm -f $OUT/model-001-0.json $OUT/model-001.npy
-nvidia-smi >/dev/null 2>&1; rocm-smi --showmeminfo vram 2>/dev/null | head -8
+rocm-smi --showmeminfo vram 2>/dev/null | head -8
