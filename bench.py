@@ -298,8 +298,8 @@ def main():
                                % args.iters_per_step,
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
                        "select_budget": args.select_budget,
-                       "setup": ("slots loaded with the positions of a generator 300 s into this workload (%s, mean ply %.0f), "
-                                 "trees grown for %d untimed iterations, then the warm-up"
+                       "setup": ("slots loaded with steady-state positions built from one complete generation of real games of "
+                                 "this workload (%s, mean ply %.0f), trees grown for %d untimed iterations, then the warm-up"
                                  % (ages["source"], ages["mean_ply"], args.phase_fill)) if ages else "cold start",
                        "net": "%dx128" % args.blocks,
                        "parallelism": "%d independent game shards, no collective" % group.world},
