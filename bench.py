@@ -134,8 +134,7 @@ def measure(sp, args, steps, warmup, group=None):
     if group is not None:
         group.barrier()
     st1 = sp.stats()
-    measure.finished_per_step = per_step[warmup:]
-    return {k: st1[k] - st0[k] for k in st1}, finished, t1 - t0, sp.timing()
+    return {k: st1[k] - st0[k] for k in st1}, finished, t1 - t0, sp.timing(), per_step[warmup:]
 
 
 SNAPSHOT = os.path.join("profiles", "round2_steady_state_positions.npz")
@@ -174,7 +173,7 @@ def target_leg(conv, bn, args, games=16384, steps=2, warmup=1):
                            select_budget=args.select_budget)
     try:
         spread(sp, args, selfplay.DEFAULT_SEED + 77)
-        d, finished, dt, tm = measure(sp, args, steps, warmup)
+        d, finished, dt, tm, _ = measure(sp, args, steps, warmup)
         it = max(tm["iterations"], 1)
         iters = steps * args.iters_per_step
         tf = d["nn_evals"] / float(iters) * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] / it * 1e-3) / 1e12
@@ -267,7 +266,7 @@ def main():
                            seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank), streams=args.streams,
                            select_budget=args.select_budget)
     ages = spread(sp, args, distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank))
-    d, finished, dt, tm = measure(sp, args, args.steps, args.warmup, group)
+    d, finished, dt, tm, finished_per_step = measure(sp, args, args.steps, args.warmup, group)
     steps_total, t_max, rate = distrib.aggregate(group, d["steps"], dt)
     evals_total = group.reduce(d["nn_evals"], "sum")
     plies_total = group.reduce(d["plies"], "sum")
@@ -308,7 +307,7 @@ def main():
             "games_per_s": games_total / t_max,    # games finished (result 1 or 2) in the timed region, counted on the device
             "game_lines_written_in_timed_region": written_total,
             "games_finished_in_timed_region": games_total,
-            "games_finished_per_step_rank0": measure.finished_per_step,   # flat = the set-up reached steady state
+            "games_finished_per_step_rank0": finished_per_step,   # flat = the loaded state is the steady state
             "mean_plies_per_finished_game": plies_total / games_total if games_total else None,
             "roofline": {"bound": "mfma", "kernel": "%s<%s>" % ("k_tower" if args.dtype == "f32" or os.environ.get("AZH_TOWER") == "1" else "k_tower2", args.dtype), "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
