@@ -31,6 +31,7 @@ Writes data-only fixtures next to this script:
                           ply -> set_state): root visits found after every set_state (tree reuse never happens)
   train_samples.npz       train.get_sample_from_entries (train.py:43-77) under random.seed(k) on
                           train_entries.json (a small games file in both entry flavours)
+  ringmaster_pgn.json     uai_ringmaster.write_game_to_pgn (uai_ringmaster.py:162-180) on three game dicts + the win tally
   nn_evals_sym.npz        nn_evals.evaluate (nn_evals.py:48-62) with tests/helpers.linear_evals injected
 """
 import array
@@ -402,6 +403,46 @@ def sym_fixture():
     return len(boards)
 
 
+def pgn_fixture():
+    """uai_ringmaster.write_game_to_pgn (uai_ringmaster.py:162-180) on three hand-made game dicts, and the scoring rule
+    of its main loop (:251-257) applied to them."""
+    import argparse
+    import tempfile
+    import uai_ringmaster
+    dec = uai_interface.uai_decode_move
+    games = [
+        {"white": ["python", "uai_interface.py", "--network-path", "a.npy", "--visits", "100"],
+         "black": ["python", "uai_interface.py", "--network-path", "b.npy", "--visits", "100"],
+         "opening": [], "start_time": 1700000000.0, "end_time": 1700000042.5,
+         "moves": [dec(m) for m in ("a7b6", "g7f6", "b6", "f5")], "result": 1, "final_score": (30, 19)},
+        {"white": ["engine", "two"], "black": ["engine", "one"], "opening": [], "start_time": 1700000100.0,
+         "end_time": 1700000101.0, "moves": [dec(m) for m in ("g1", "a1a3")], "result": 2, "final_score": (0, 7)},
+        {"white": ["x"], "black": ["y"], "opening": [], "start_time": 1700000200.0, "end_time": 1700000300.0,
+         "moves": [dec("b7")] * 3, "result": "invalid", "final_score": (5, 5)},
+    ]
+    args = argparse.Namespace(tc=1.0)
+    texts = []
+    for i, g in enumerate(games):
+        with tempfile.NamedTemporaryFile("r", suffix=".pgn") as f:
+            uai_ringmaster.write_game_to_pgn(args, f.name, g, round_index=i + 1)
+            texts.append(open(f.name).read())
+    wins = {"white": 0, "black": 0}
+    annulled = 0
+    for g in games:   # uai_ringmaster.py:251-257 (both sides are scored per colour here)
+        if g["result"] in (1, 2):
+            wins[("white", "black")[g["result"] - 1]] += 1
+        else:
+            wins["white"] += 0.5
+            wins["black"] += 0.5
+            annulled += 1
+    out = [{"white": " ".join(g["white"]), "black": " ".join(g["black"]), "moves": [enc(m) for m in g["moves"]],
+            "result": 0 if g["result"] == "invalid" else g["result"], "final_score": list(g["final_score"]), "pgn": t}
+           for g, t in zip(games, texts)]
+    with open(os.path.join(HERE, "ringmaster_pgn.json"), "w") as f:
+        json.dump({"tc": 1.0, "games": out, "wins": wins, "annulled": annulled}, f)
+    return len(out)
+
+
 def main():
     if os.environ.get("PYTHONHASHSEED") != "0":
         print("note: run with PYTHONHASHSEED=0 for byte-stable output (clone moves come out of a set, "
@@ -419,6 +460,7 @@ def main():
     print("reuse: inherited root visits per ply:", [p["inherited_root_visits"] for p in plies])
     print("train samples:", train_fixture())
     print("sym boards:", sym_fixture())
+    print("pgn games:", pgn_fixture())
 
 
 if __name__ == "__main__":

@@ -132,3 +132,20 @@ def test_tree_reuse_across_moves_equals_mcts_play():
         assert st["reroot_nodes"] > len(rec["plies"])   # subtrees were kept, not rebuilt
         inherited += sum(p["root_visits"] - p["steps"] for p in rec["plies"][1:])
     assert inherited > 1000
+
+
+def test_pgn_blocks_equal_the_reference_ringmaster(tmp_path):
+    # arena.write_game_to_pgn against uai_ringmaster.write_game_to_pgn (uai_ringmaster.py:162-180): tag for tag, except
+    # the three lines that carry wall-clock times
+    from ataxxzero_amd import arena
+    with open(os.path.join(GOLDEN, "ringmaster_pgn.json")) as f:
+        fixture = json.load(f)
+    clock = ("[Date ", "[GameStartTime ", "[GameEndTime ")
+    for i, g in enumerate(fixture["games"]):
+        path = str(tmp_path / ("g%d.pgn" % i))
+        arena.write_game_to_pgn(path, {"moves": g["moves"], "result": g["result"], "final_score": g["final_score"]},
+                                g["white"], g["black"], i + 1, fixture["tc"])
+        got = [l for l in open(path).read().split("\n") if not l.startswith(clock)]
+        want = [l for l in g["pgn"].split("\n") if not l.startswith(clock)]
+        assert got == want
+        assert sum(l.startswith(clock) for l in open(path).read().split("\n")) == 3

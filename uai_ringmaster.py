@@ -65,7 +65,9 @@ if __name__ == "__main__":
     concurrent = args.concurrent or min(2048, args.game_count + args.game_count % 2)
     concurrent += concurrent % 2
     match = arena.Match(model.load_model(path_a), model.load_model(path_b), visits_a, games=concurrent, dtype=args.dtype,
-                        seed=args.seed, max_plies=args.max_plies if args.max_plies is not None else 400)
+                        seed=args.seed,
+                        # the reference stops a game once ply_number > --max-plies (uai_ringmaster.py:139-140): N + 1 moves
+                        max_plies=args.max_plies + 1 if args.max_plies is not None else 400)
     names = {"a": " ".join(engines[0]), "b": " ".join(engines[1])}
     wins = {"a": 0, "b": 0}
     annulled = 0
