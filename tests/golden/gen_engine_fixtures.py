@@ -31,6 +31,7 @@ Writes data-only fixtures next to this script:
                           ply -> set_state): root visits found after every set_state (tree reuse never happens)
   train_samples.npz       train.get_sample_from_entries (train.py:43-77) under random.seed(k) on
                           train_entries.json (a small games file in both entry flavours)
+  random_play_games.jsonl.gz  six games of generate_games.generate_game --random-play (generate_games.py:16-75), as written
   ringmaster_pgn.json     uai_ringmaster.write_game_to_pgn (uai_ringmaster.py:162-180) on three game dicts + the win tally
   nn_evals_sym.npz        nn_evals.evaluate (nn_evals.py:48-62) with tests/helpers.linear_evals injected
 """
@@ -443,6 +444,32 @@ def pgn_fixture():
     return len(out)
 
 
+def random_play_fixture():
+    """generate_games.generate_game with --random-play (generate_games.py:16-75), six games under random.seed(0..5), each
+    dumped the way the script's write loop dumps it (json.dump, default separators, :134-136)."""
+    import argparse
+    import io
+    import generate_games
+    args = argparse.Namespace(random_play=True, supervised=None, show_game=False, die_if_present=None, group_index=0,
+                              visit_count=0)
+    lines = []
+    stdout = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        for seed in range(6):
+            random.seed(seed)
+            entry = generate_games.generate_game(args)
+            buf = io.StringIO()
+            json.dump(entry, buf)
+            lines.append(buf.getvalue())
+    finally:
+        sys.stdout.close()
+        sys.stdout = stdout
+    with gzip.GzipFile(os.path.join(HERE, "random_play_games.jsonl.gz"), "wb", mtime=0) as f:
+        f.write(("\n".join(lines) + "\n").encode())
+    return [len(json.loads(l)["moves"]) for l in lines]
+
+
 def main():
     if os.environ.get("PYTHONHASHSEED") != "0":
         print("note: run with PYTHONHASHSEED=0 for byte-stable output (clone moves come out of a set, "
@@ -461,6 +488,7 @@ def main():
     print("train samples:", train_fixture())
     print("sym boards:", sym_fixture())
     print("pgn games:", pgn_fixture())
+    print("random-play games (plies):", random_play_fixture())
 
 
 if __name__ == "__main__":

@@ -149,3 +149,51 @@ def test_pgn_blocks_equal_the_reference_ringmaster(tmp_path):
         want = [l for l in g["pgn"].split("\n") if not l.startswith(clock)]
         assert got == want
         assert sum(l.startswith(clock) for l in open(path).read().split("\n")) == 3
+
+
+def _reference_random_games():
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, "random_play_games.jsonl.gz")) as f:
+        return [l for l in f.read().decode().split("\n") if l.strip()]
+
+
+def _shape(v):
+    """Structure of a JSON value: types and nesting, lists summarised by the set of their element shapes."""
+    if isinstance(v, dict):
+        return {k: _shape(x) for k, x in v.items()}
+    if isinstance(v, list):
+        return ["list", sorted({json.dumps(_shape(x), sort_keys=True) for x in v})]
+    return type(v).__name__
+
+
+def test_reference_random_play_games_replay_through_the_oracle_rules():
+    """Six whole games written by the reference's own generate_games.py --random-play: every recorded board, every move
+    and the result must be what the oracle's rules produce — movegen, makemove with captures and adjudication checked
+    along complete reference games, in the reference's own file format."""
+    from ataxxzero_amd import selfplay
+    from tests.helpers import replay_game_entry
+    lines = _reference_random_games()
+    assert len(lines) == 6
+    for line in lines:
+        entry = json.loads(line)
+        assert list(entry) == ["boards", "moves", "result"] and entry["result"] in (1, 2)
+        sq = lambda xy: "abcdefg"[xy[0]] + str(7 - xy[1])
+        uai = [sq(m[1]) if m[0] == "c" else sq(m[0]) + sq(m[1]) for m in entry["moves"]]
+        assert replay_game_entry({"boards": entry["boards"], "moves": uai}, orc.START_FEN_PLAIN) == entry["result"]
+        # the product's encoder writes the reference's move values: u16 move -> nested lists
+        for m, text in zip(entry["moves"], uai):
+            assert selfplay.python_move(orc.move_from_string(text)) == m
+
+
+def test_random_play_entry_format_is_the_reference_format():
+    # keys, their order, nesting and element types of a reference line (generate_games.py:50-51,:68,:134-136) against an
+    # entry assembled by the product's own encoders (the GPU CLI is compared the same way in tests/test_gpu_cli.py)
+    from ataxxzero_amd import selfplay
+    ref = json.loads(_reference_random_games()[0])
+    p = orc.pos_from_fen(orc.START_FEN_PLAIN)
+    moves = orc.movegen(p)
+    ours = {"boards": [selfplay.board_cells(int(p.pieces[0]), int(p.pieces[1]))] * 2,
+            "moves": [selfplay.python_move(int(moves[0])), selfplay.python_move(int(moves[-1]))], "result": 2}
+    assert {moves[0] & 0xFF == moves[0] >> 8, moves[-1] & 0xFF == moves[-1] >> 8} == {True, False}   # a jump and a clone
+    assert _shape(ours) == _shape(ref) and list(ours) == list(ref)
+    assert ours["boards"][0] == ref["boards"][0]                      # both start from ataxx_rules.AtaxxState.initial()

@@ -112,6 +112,15 @@ def test_generate_games_random_play_cli(tmp_path):
         assert replay_game_entry(e2, orc.START_FEN_PLAIN) == entry["result"]
         plies.append(len(uai))
     assert 100 < np.mean(plies) < 260  # reference random play averages 182 plies
+    # line for line the structure of what the reference's own generate_games.py writes (tests/golden/random_play_games.jsonl.gz)
+    from tests.test_engine_fixtures_oracle import _reference_random_games, _shape
+    ref_line = _reference_random_games()[0]
+    ref = json.loads(ref_line)
+    for line in lines[:20]:
+        entry = json.loads(line)
+        assert _shape(entry) == _shape(ref) and list(entry) == list(ref)
+        assert json.dumps(entry) == line.rstrip("\n")                  # json.dump with its default separators, like ref_line
+    assert json.dumps(ref) == ref_line
 
 
 def test_two_half_batches_match_two_independent_engines():
