@@ -140,3 +140,40 @@ def test_detmath_bits_match_oracle():
     assert (got == want).all()
     g = got.view(np.float32).astype(np.float64)
     assert abs(g.mean() - 0.15) < 0.03 and abs(g.var() - 0.15) < 0.06  # Gamma(0.15, 1): mean = var = 0.15
+
+
+def test_reference_random_play_games_replay_on_the_gpu():
+    """Six whole games written by the reference's generate_games.py --random-play (tests/golden/random_play_games.jsonl.gz):
+    for every ply the GPU must list the played move as legal, adjudicate the position as ongoing, and make-move must
+    give the next recorded board; the last move must end the game with the recorded result."""
+    import json
+    from tests.test_engine_fixtures_oracle import _reference_random_games
+
+    def pack(cells, ply):
+        x = o = 0
+        for idx, v in enumerate(cells):
+            sq = (idx % 7) + 7 * (6 - idx // 7)
+            if v == 1:
+                x |= 1 << sq
+            elif v == 2:
+                o |= 1 << sq
+        return [x | ((ply & 1) << 63), o]
+
+    sq = lambda xy: xy[0] + 7 * (6 - xy[1])
+    total = 0
+    for line in _reference_random_games():
+        entry = json.loads(line)
+        n = len(entry["moves"])
+        boards = np.array([pack(b, p) for p, b in enumerate(entry["boards"])], dtype=np.uint64)
+        moves = np.array([sq(m[1]) | (sq(m[1]) << 8) if m[0] == "c" else sq(m[0]) | (sq(m[1]) << 8) for m in entry["moves"]],
+                         dtype=np.uint16)
+        legal, counts, results = link.rules_batch(boards, 0)
+        assert (results == 0).all()
+        for p in range(n):
+            assert moves[p] in legal[p, :counts[p]]
+        nxt = link.makemove_batch(boards, moves)
+        assert (nxt[:-1] == boards[1:]).all()
+        _, _, last = link.rules_batch(nxt[-1:], 0)
+        assert int(last[0]) == entry["result"]
+        total += n
+    assert total == 1134
