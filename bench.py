@@ -152,10 +152,8 @@ def spread(sp, args, seed):
     import numpy as np
     snap = np.load(os.path.join(ROOT, SNAPSHOT))
     boards, plies = snap["boards"], snap["plies"]
-    if sp.games == len(plies):
-        pick = np.arange(len(plies))
-    else:
-        pick = np.random.default_rng(seed).integers(0, len(plies), size=sp.games)
+    rng = np.random.default_rng(seed)   # per-rank seed: every shard gets its own assignment of positions to slots
+    pick = rng.permutation(len(plies)) if sp.games == len(plies) else rng.integers(0, len(plies), size=sp.games)
     sp.set_positions(boards[pick], plies[pick])
     done = 0
     while done < args.phase_fill:
