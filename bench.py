@@ -197,9 +197,22 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # a rank that dies would leave the others waiting at a barrier for ever: watch them all, and take the job down
+    # with the first failure
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
