@@ -257,6 +257,8 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, group.world))
 
     if args.plumbing_selftest:
+        if os.environ.get("AZH_SELFTEST_FAIL_RANK") == str(group.rank):
+            raise SystemExit(3)   # rehearse a rank dying before the barrier (tests/test_distrib_gloo.py)
         group.barrier()
         units, secs = 1000.0 * (group.rank + 1), 1.0 + group.rank
         total, t_max, rate = distrib.aggregate(group, units, secs)

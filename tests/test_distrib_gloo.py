@@ -78,6 +78,17 @@ def test_bench_py_starts_its_own_ranks_and_aggregates():
     assert out["seeds"] == [20260101, 20260102]
 
 
+def test_bench_py_fails_fast_when_a_rank_dies():
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["AZH_SELFTEST_FAIL_RANK"] = "1"
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest"],
+                         env=env, capture_output=True, timeout=120)
+    assert res.returncode != 0 and b"rank 1 -> exit 3" in res.stderr
+    assert time.time() - t0 < 60   # rank 0 was not left waiting at the barrier
+
+
 def test_bench_py_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest"],
