@@ -83,7 +83,8 @@ def cpu_baseline(net, visits, dtype, seconds):
 
     # the evaluator leg gets the buffer size that suits it best: a larger batch amortises the per-call cost of the
     # host-buffer evaluator (the reference's default is 128 rows, accelerated_generate_games.py:20)
-    legs = [driver.run(tower, visits, b, seconds / 2.0) for b in (256, 1024)]
+    # (at most 896 game threads: the GPU boxes allow about a thousand tasks per job)
+    legs = [driver.run(tower, visits, b, seconds / 2.0) for b in (256, 448)]
     full = max(legs, key=lambda r: r["steps_per_s"])
     B = full["buffer_entries"]
     null_all = driver.run(None, visits, 256, min(seconds, 5.0))
