@@ -107,6 +107,20 @@ def cpu_baseline(net, visits, dtype, seconds):
                       % (full["threads"], B, visits, full["seconds"], dtype)}
 
 
+def vendor_gemm_ceiling():
+    """Dense bf16 GEMM through the vendor library (torch.matmul -> hipBLASLt) on random data, on this box, right after the
+    timed region: what an MFMA-dense kernel reaches here under the chip's power limit (the 2.5 PFLOP/s peak assumes
+    2.4 GHz).  Context for roofline.frac, never a replacement for `peak`."""
+    try:
+        from tools.gemm_ceiling import gemm
+        import torch
+        shapes = ((8192, 8192, 8192), (4096, 4096, 16384))
+        return {"unit": "TFLOP/s", "what": "torch.matmul bf16, random data, best of %s" % (shapes,),
+                "value": max(gemm(m, n, k, torch.bfloat16, iters=20) for m, n, k in shapes)}
+    except Exception as e:   # context only: never fail the bench for it
+        return {"error": repr(e)}
+
+
 def measure(sp, args, steps, warmup, group=None):
     """`warmup` untimed steps, then EXACTLY `steps` timed steps between barriers + device syncs."""
     per_step = []
@@ -241,6 +255,8 @@ def main():
                          "descents park and resume next iteration, so a launch does not last as long as the deepest "
                          "line of the batch; every game still plays exactly the same search")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-ceiling", action="store_true",
+                    help="skip the vendor-library bf16 GEMM measured beside the roofline (context for roofline.frac)")
     ap.add_argument("--no-target-leg", action="store_true", help="skip the 16384-game leg reported beside the headline")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--plumbing-selftest", action="store_true",
@@ -339,6 +355,8 @@ def main():
         sp.close()
         if group.world == 1 and not args.no_target_leg and args.streams == 1:
             out["target_10k_games"] = target_leg(conv, bn, args)
+        if group.world == 1 and not args.no_gemm_ceiling:
+            out["roofline"]["vendor_gemm_on_this_box"] = vendor_gemm_ceiling()
         if group.world == 1 and not args.no_cpu_baseline:
             net = link.Net(conv, bn)
             out["cpu_baseline"] = cpu_baseline(net, args.visits, args.dtype, args.cpu_seconds)

@@ -320,6 +320,7 @@ def test_bench_contract_line():
     assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0 < r["launches_timed"] <= r["launches_in_region"] == 300
     assert r["avg_launch_ms"] < d["ms_per_iteration"]
+    assert r["vendor_gemm_on_this_box"]["value"] > 100   # the library's bf16 GEMM on this box, measured beside the tower
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["null_evaluator_value"] > 0
 

@@ -6,8 +6,8 @@ show() { python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$1: %.3f M node-evals/s  %.3f ms/iteration  tower %.1f%% of peak  tree %.3f ms  plies/s %.0f  games/s %.1f' % (d['value']/1e6, d['ms_per_iteration'], 100*d['roofline']['frac'], d['tree_roofline']['tree_phase_ms_per_iteration'], d['plies_per_s'], d['games_per_s']))"; }
-timeout -k 10 280 python3 bench.py --visits 200 --no-cpu-baseline --no-target-leg | show "C2  4096 games, 200 sims, 12x128 bf16" || exit 1
-timeout -k 10 400 python3 bench.py --visits 800 --blocks 8 --dtype f16 --no-cpu-baseline --no-target-leg | show "C4  4096 games, 800 sims,  8x128 f16 " || exit 2
+timeout -k 10 280 python3 bench.py --visits 200 --no-cpu-baseline --no-target-leg --no-gemm-ceiling | show "C2  4096 games, 200 sims, 12x128 bf16" || exit 1
+timeout -k 10 400 python3 bench.py --visits 800 --blocks 8 --dtype f16 --no-cpu-baseline --no-target-leg --no-gemm-ceiling | show "C4  4096 games, 800 sims,  8x128 f16 " || exit 2
 python3 - <<PY
 import sys; sys.path.insert(0, "$R")
 from ataxxzero_amd import model

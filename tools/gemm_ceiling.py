@@ -6,12 +6,11 @@ import os
 import sys
 import time
 
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def gemm(m, n, k, dtype, iters=30):
+    import torch
     a = torch.randn(m, k, device="cuda", dtype=dtype)
     b = torch.randn(k, n, device="cuda", dtype=dtype)
     for _ in range(5):
@@ -26,6 +25,7 @@ def gemm(m, n, k, dtype, iters=30):
 
 
 def main():
+    import torch
     best = 0.0
     for shape in ((8192, 8192, 8192), (16384, 8192, 4096), (4096, 4096, 16384), (16384, 16384, 2048),
                   # the tower's own GEMM per layer at 16 K boards: M = cells, N = 128 channels, K = 9 * 128

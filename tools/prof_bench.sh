@@ -4,7 +4,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_bench
-ARGS=${ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-target-leg}
+ARGS=${ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-target-leg --no-gemm-ceiling}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
