@@ -110,13 +110,12 @@ def cpu_baseline(net, visits, dtype, seconds):
 def vendor_gemm_ceiling():
     """Dense bf16 GEMM through the vendor library (torch.matmul -> hipBLASLt) on random data, on this box, right after the
     timed region: what an MFMA-dense kernel reaches here under the chip's power limit (the 2.5 PFLOP/s peak assumes
-    2.4 GHz).  Context for roofline.frac, never a replacement for `peak`."""
+    2.4 GHz).  Context for roofline.frac, never a replacement for `peak`.  Runs in a child process: torch brings its own
+    HIP runtime, which must not be initialised after this process's."""
     try:
-        from tools.gemm_ceiling import gemm
-        import torch
-        shapes = ((8192, 8192, 8192), (4096, 4096, 16384))
-        return {"unit": "TFLOP/s", "what": "torch.matmul bf16, random data, best of %s" % (shapes,),
-                "value": max(gemm(m, n, k, torch.bfloat16, iters=20) for m, n, k in shapes)}
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_ceiling.py"), "--json"],
+                             capture_output=True, timeout=600)
+        return json.loads(res.stdout.decode().strip().splitlines()[-1])
     except Exception as e:   # context only: never fail the bench for it
         return {"error": repr(e)}
 
