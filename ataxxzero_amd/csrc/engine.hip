@@ -50,8 +50,9 @@ struct EngineParams {
     int start_turn;
     u32 flags;
     int select_budget;  // tree levels per select launch and game (0 = unlimited), azh_config.select_budget
-    int *no_emit;        // [G] 1 = the slot's current game was started from a loaded position (azh_engine_set_positions):
-                         // it is played and counted, but its record would lack the plies before the start, so it is not written
+    int *no_emit;        // [G] start ply + 1 when the slot's current game was started from a loaded position
+                         // (azh_engine_set_positions), else 0: such a game is played, counted and its record assembled and
+                         // handed to the host like any other, but it lacks the plies before the start, so no line is written
     azh_game_state *gs;
     int *force;
     int *adv_list;   // games whose move is due (phase 2), appended by mark_game, consumed by k_advance_list
@@ -144,7 +145,7 @@ __device__ inline void init_game_at(const EngineParams &P, int g, u32 uid, azh_g
         A.nb[0] = make_ulonglong2(pack_word0(b), b.o);
         A.ni[0] = make_uint4(0u, (u32)M | ((u32)res << 16), 0u, 0u);
         P.force[g] = 0;
-        P.no_emit[g] = loaded;
+        P.no_emit[g] = loaded ? ply + 1 : 0;
     }
     __syncthreads();
     s.phase = 0;
@@ -872,21 +873,17 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
             out[4] = 0; out[5] = 8; out[6] = 0; out[7] = 1;  // word 7: dropped
         }
     };
-    const bool loaded = P.no_emit[g] != 0;  // started from a loaded position: counted, not written (its first plies are missing)
+    const int loaded = P.no_emit[g];            // start ply + 1 of a game that began at a loaded position, else 0
+    const int p0 = loaded ? loaded - 1 : 0;     // first ply this game recorded
     if (no_sample) {
         st_dropped = 1;
-        drop_marker();
-        init_game(P, g, s.uid + (u32)P.G, s, s_moves);
-    } else if (loaded && (result != 0 || cut)) {
-        st_games = result != 0 ? 1 : 0;
-        st_dropped = result != 0 ? 0 : 1;
         drop_marker();
         init_game(P, g, s.uid + (u32)P.G, s, s_moves);
     } else if (result != 0 || (cut && (P.flags & AZH_FLAG_KEEP_UNFINISHED))) {
         // finished: emit the packed record (generate_game :577-578, Worker :637-642)
         const u32 *recg = P.rec + (size_t)g * P.max_plies * REC_STRIDE_WORDS;
         int words = 0;
-        for (int p = lane; p < s.ply; p += WAVE)
+        for (int p = p0 + lane; p < s.ply; p += WAVE)
             words += 6 + (int)(recg[(size_t)p * REC_STRIDE_WORDS + 4] >> 16);
         words = wave_sum_int(words) + 8;
         u64 off = 0;
@@ -899,14 +896,14 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
                 out[0] = RING_MAGIC;
                 out[1] = (u32)g;
                 out[2] = s.uid;
-                out[3] = (u32)s.ply;
+                out[3] = (u32)(s.ply - p0);   // plies in the record
                 out[4] = (u32)result;
                 out[5] = (u32)words;
                 out[6] = (P.flags & AZH_FLAG_ONE_RANDOM_MOVE) ? (u32)random_ply_of(P, s.uid) + 1u : 0u;
-                out[7] = 0;
+                out[7] = loaded ? 2u : 0u;    // 2: partial game (begins at a loaded position): formatted by the host, not written
             }
             u32 pos = 8;
-            for (int p = 0; p < s.ply; p++) {
+            for (int p = p0; p < s.ply; p++) {
                 const u32 *rp = recg + (size_t)p * REC_STRIDE_WORDS;
                 const u32 ndp = rp[4] >> 16;
                 if (lane < 6)
@@ -1574,10 +1571,14 @@ extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int6
             for (auto &o : order) {
                 const uint32_t *rec = host.data() + o.second;
                 const bool dropped = rec[7] == 1;
+                std::string line = dropped ? std::string() : azh_format_game_json(rec, rec[5], ids);
+                if (rec[7] == 2)
+                    line.clear();  // a game that began at a loaded position: record drained and formatted like any other
+                                   // (the measured path does the same work per finished game), but it is not a whole game
                 if (e->emit_by_uid)
-                    e->held[o.first] = dropped ? std::string() : azh_format_game_json(rec, rec[5], ids);
-                else if (!dropped)
-                    e->pending.push_back(azh_format_game_json(rec, rec[5], ids));
+                    e->held[o.first] = std::move(line);
+                else if (!line.empty())
+                    e->pending.push_back(std::move(line));
             }
             if (e->emit_by_uid) {
                 for (auto it = e->held.begin(); it != e->held.end() && it->first == e->next_uid; it = e->held.erase(it)) {

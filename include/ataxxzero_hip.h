@@ -214,9 +214,10 @@ int azh_engine_sync(azh_engine *e);
 int azh_engine_set_visits(azh_engine *e, int visits);
 
 /* Measurement set-up hook: every slot restarts at a given position — boards [games][2] packed (x | turn << 63, o),
- * plies [games] — with a fresh tree.  Such games are played and counted (AZH_STAT_GAMES / _DROPPED) but not written: their
- * records would lack the plies before the start.  bench.py loads the positions a long-running generator was found at
- * instead of waiting a game generation (about 70 s at 400 sims/move) for the steady state to form. */
+ * plies [games] — with a fresh tree.  Such games are played, counted (AZH_STAT_GAMES / _DROPPED), and their records are
+ * assembled, drained and formatted like any other (the measured path does the same work per finished game), but no line is
+ * handed out: the record lacks the plies before the start.  bench.py loads the positions a long-running generator would
+ * be found at instead of waiting a game generation (about 70 s at 400 sims/move) for the steady state to form. */
 int azh_engine_set_positions(azh_engine *e, const uint64_t *boards, const int32_t *plies);
 
 int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out);
