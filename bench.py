@@ -114,7 +114,7 @@ def vendor_gemm_ceiling():
     HIP runtime, which must not be initialised after this process's."""
     try:
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_ceiling.py"), "--json"],
-                             capture_output=True, timeout=600)
+                             capture_output=True, timeout=300)   # (a first `import torch` on a fresh box can take a minute)
         return json.loads(res.stdout.decode().strip().splitlines()[-1])
     except Exception as e:   # context only: never fail the bench for it
         return {"error": repr(e)}
