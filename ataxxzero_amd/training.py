@@ -136,7 +136,8 @@ def load_entries(paths):
     return entries
 
 
-def make_minibatch(entries, size):
+def make_minibatch_reference(entries, size):
+    """`size` samples drawn one by one with get_sample_from_entries (train.py:123-130)."""
     feats, pols, vals = [], [], []
     for _ in range(size):
         f, p, v = get_sample_from_entries(entries)
@@ -144,6 +145,103 @@ def make_minibatch(entries, size):
         pols.append(p)
         vals.append(v)
     return (np.asarray(feats, dtype=np.float32), np.asarray(pols, dtype=np.float32), np.asarray(vals, dtype=np.float32))
+
+
+def _symmetry_tables():
+    """For each of the 8 symmetries: which recorded cell (index x + 7 y) every feature cell [x][y] shows, and where every
+    flat policy index 119 x + 17 y + layer goes — both read off apply_symmetry / apply_symmetry_to_move themselves."""
+    cell_of = np.arange(BOARD * BOARD, dtype=np.int64).reshape(BOARD, BOARD).T[..., None]      # [x][y] -> x + 7 y
+    cell_src = np.stack([apply_symmetry(s, cell_of)[..., 0].reshape(-1) for s in range(8)])       # [s][x * 7 + y]
+    policy_to = np.zeros((8, BOARD * BOARD * MOVE_TYPES), dtype=np.int64)
+    probe = np.zeros((BOARD, BOARD, MOVE_TYPES))
+
+    def flat(move):
+        probe[...] = 0
+        add_move_to_heatmap(probe, move)
+        return int(np.flatnonzero(probe.ravel())[0])
+
+    for x in range(BOARD):
+        for y in range(BOARD):
+            moves = [("c", (x, y))] + [((x - dx, y - dy), (x, y)) for dx, dy in FAR_OFFSETS
+                                       if 0 <= x - dx < BOARD and 0 <= y - dy < BOARD]
+            for m in moves:
+                for s in range(8):
+                    policy_to[s, flat(m)] = flat(apply_symmetry_to_move(s, m))
+    return cell_src, policy_to
+
+
+_TABLES = None
+
+
+def _entry_arrays(entry):
+    """Per-entry arrays for the batched pipeline, built once: cells [plies][49] and, per ply, the flat policy indices
+    and weights of its target (the visit distribution, or the move played)."""
+    cache = entry.get("_arrays")
+    if cache is None:
+        cells = np.asarray(entry["boards"], dtype=np.int8)
+        probe = np.zeros((BOARD, BOARD, MOVE_TYPES))
+        idx, wts, start = [], [], [0]
+        for ply in range(len(entry["boards"])):
+            if "dists" in entry:
+                items = entry["dists"][ply].items()
+            else:
+                items = [(entry["moves"][ply], 1)]
+            for mv, w in items:
+                if mv == "pass":
+                    continue
+                if isinstance(mv, str):
+                    mv = uai_decode_move(mv)
+                else:
+                    mv = (mv[0] if mv[0] == "c" else tuple(mv[0]), tuple(mv[1]))
+                probe[...] = 0
+                add_move_to_heatmap(probe, mv)
+                idx.append(int(np.flatnonzero(probe.ravel())[0]))
+                wts.append(w)
+            start.append(len(idx))
+        cache = entry["_arrays"] = (cells, np.asarray(idx, dtype=np.int64), np.asarray(wts, dtype=np.float64),
+                                    np.asarray(start, dtype=np.int64))
+    return cache
+
+
+def make_minibatch(entries, size):
+    """The same `size` samples as make_minibatch_reference — same draws from `random` in the same order, bit-identical
+    arrays (tests/test_training.py) — assembled with array operations instead of per-sample Python: the sample pipeline,
+    not the GPU step, bounded train.py's rate."""
+    global _TABLES
+    if _TABLES is None:
+        _TABLES = _symmetry_tables()
+    cell_src, policy_to = _TABLES
+    cells, movers, syms, results, rows, pidx, pw = [], [], [], [], [], [], []
+    while len(cells) < size:
+        entry = random.choice(entries)                      # the reference's draws, in its order (train.py:45-60)
+        ply = random.randrange(len(entry["boards"]))
+        if "random_ply" in entry:
+            ply = entry["random_ply"] + 1
+        if entry["moves"][ply] == "pass":
+            continue
+        sym = random.randrange(8)
+        c, idx, wts, start = _entry_arrays(entry)
+        lo, hi = start[ply], start[ply + 1]
+        rows.append(np.full(hi - lo, len(cells), dtype=np.int64))
+        pidx.append(policy_to[sym, idx[lo:hi]])
+        pw.append(wts[lo:hi])
+        cells.append(c[ply])
+        movers.append(1 + ply % 2)
+        syms.append(sym)
+        results.append(entry["result"])
+    cells = np.stack(cells)
+    movers = np.asarray(movers, dtype=np.int8)[:, None]
+    shown = np.take_along_axis(cells, cell_src[np.asarray(syms)], axis=1)        # [b][x * 7 + y]
+    feats = np.zeros((size, BOARD * BOARD, 4), dtype=np.float32)
+    feats[..., 0] = 1
+    feats[..., 1] = shown == movers
+    feats[..., 2] = (shown != 0) & (shown != movers)
+    pols = np.zeros((size, BOARD * BOARD * MOVE_TYPES), dtype=np.float32)
+    np.add.at(pols, (np.concatenate(rows), np.concatenate(pidx)), np.concatenate(pw).astype(np.float32))
+    if (np.abs(1 - pols.sum(axis=1)) >= 1e-3).any():
+        raise AssertionError("policy target does not sum to one")
+    vals = np.where(np.asarray(results)[:, None] == movers, 1, -1).astype(np.float32)
+    return feats.reshape(size, BOARD, BOARD, 4), pols.reshape(size, BOARD, BOARD, MOVE_TYPES), vals
 
 
 # ---------------------------------------------------------------- the network (model.py:38-101)

@@ -90,3 +90,25 @@ def test_train_cli_writes_reference_layout(tmp_path):
     assert [a.shape for a in conv2] == [a.shape for a in conv]
     assert any(not np.array_equal(a, b) for a, b in zip(conv, conv2))       # weights moved
     assert not np.array_equal(bn2[0], bn[0]) and (np.asarray(bn2[1]) > 0).all()  # moving statistics updated
+
+
+def test_batched_minibatch_is_bit_identical_to_the_sample_by_sample_pipeline():
+    """training.make_minibatch assembles a minibatch with array operations; it must draw from `random` exactly as the
+    reference's per-sample loop does (train.py:123-130) and give the same arrays bit for bit, for all entry flavours
+    (dists / one-hot nested-list moves / random_ply)."""
+    import json
+    import os
+    import random
+    from tests.helpers import GOLDEN
+    with open(os.path.join(GOLDEN, "train_entries.json")) as f:
+        entries = json.load(f)
+    for seed in range(6):
+        random.seed(seed)
+        a = training.make_minibatch_reference(entries, 200)
+        state_a = random.getstate()
+        random.seed(seed)
+        b = training.make_minibatch(entries, 200)
+        assert random.getstate() == state_a                       # the same number of draws, in the same order
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype == np.float32 and x.shape == y.shape and np.array_equal(x, y)
+    assert a[0].shape == (200, 7, 7, 4) and a[1].shape == (200, 7, 7, 17) and a[2].shape == (200, 1)
