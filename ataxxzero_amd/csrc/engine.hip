@@ -50,6 +50,8 @@ struct EngineParams {
     int start_turn;
     u32 flags;
     int select_budget;  // tree levels per select launch and game (0 = unlimited), azh_config.select_budget
+    u32 *tt;             // AZH_FLAG_EVAL_CACHE: [2][G][tt_size] open-addressed table of evaluated nodes, keyed by the board
+    int tt_size;         // power of two >= 4 * node_cap
     int *no_emit;        // [G] start ply + 1 when the slot's current game was started from a loaded position
                          // (azh_engine_set_positions), else 0: such a game is played, counted and its record assembled and
                          // handed to the host like any other, but it lacks the plies before the start, so no line is written
@@ -126,6 +128,59 @@ __device__ inline void add_stat(const EngineParams &P, int g, int k, u64 v)
         P.stats[(size_t)g * NSTAT + k] += v;
 }
 
+// ------------------------------------------------------------------ evaluation cache (AZH_FLAG_EVAL_CACHE)
+// A position the search of this game has already evaluated is not sent to the net again: engine.py's NNEvaluator.cache
+// (engine.py:127-234; the C++ generator has none).  Transpositions and re-visited positions are about a quarter of all
+// leaves at 400 sims/move.  Per game and arena an open-addressed table maps a board to a node that carries its
+// evaluation (priors on its edges, value in node_info.w); the net is deterministic, so copying that evaluation is what
+// evaluating again would give.  The root is never a source: its priors carry this ply's noise.
+__host__ __device__ inline u32 tt_hash(u64 w0, u64 w1, u32 mask)
+{
+    const u64 k = (w0 * 0x9E3779B97F4A7C15ULL) ^ ((w1 + 0x7F4A7C15ULL) * 0xC2B2AE3D27D4EB4FULL);
+    return (u32)(k >> 40) & mask;
+}
+
+__device__ inline u32 *tt_of(const EngineParams &P, int a, int g)
+{
+    return P.tt + ((size_t)a * P.G + g) * (size_t)P.tt_size;
+}
+
+// Node holding the evaluation of board (w0, w1), or NONE.  Wave-wide: lane l looks at slot h + l (the chain up to the
+// first empty slot is searched in one round trip for the slots and one for the candidates' boards).
+__device__ inline u32 tt_lookup(const u32 *tt, u32 mask, const Arena &A, u64 w0, u64 w1)
+{
+    const int lane = lane_id();
+    const u32 id = tt[(tt_hash(w0, w1, mask) + (u32)lane) & mask];
+    const u64 empties = __ballot(id == NONE);
+    const u64 before = empties ? (empties & (0ULL - empties)) - 1ULL : ~0ULL;  // lanes ahead of the first empty slot
+    bool match = false;
+    if (((before >> lane) & 1ULL) && id != NONE) {
+        const ulonglong2 b = A.nb[id];
+        match = b.x == w0 && b.y == w1;
+    }
+    const u64 hits = __ballot(match);
+    if (!hits)
+        return NONE;
+    return (u32)read_lane((int)id, __ffsll((long long)hits) - 1);
+}
+
+// One lane enters `id` under its board (linear probing; several lanes of the wave may insert at once).
+__device__ inline void tt_insert(u32 *tt, u32 mask, u64 w0, u64 w1, u32 id)
+{
+    u32 slot = tt_hash(w0, w1, mask);
+    for (u32 tries = 0; tries <= mask; tries++) {
+        if (atomicCAS(&tt[slot], NONE, id) == NONE)
+            return;
+        slot = (slot + 1) & mask;
+    }
+}
+
+__device__ inline void tt_clear(u32 *tt, int size)
+{
+    for (int i = lane_id(); i < size; i += WAVE)
+        tt[i] = NONE;
+}
+
 // Fresh tree at the start position in arena 0 (generate_game :510-512,
 // MCTS::init_from_scratch :380-383).  Wave-cooperative; s_moves is LDS scratch.
 __device__ inline void init_game_at(const EngineParams &P, int g, u32 uid, azh_game_state &s, u16 *s_moves, Board b, int ply,
@@ -147,6 +202,8 @@ __device__ inline void init_game_at(const EngineParams &P, int g, u32 uid, azh_g
         P.force[g] = 0;
         P.no_emit[g] = loaded ? ply + 1 : 0;
     }
+    if (P.flags & AZH_FLAG_EVAL_CACHE)
+        tt_clear(tt_of(P, 0, g), P.tt_size);
     __syncthreads();
     s.phase = 0;
     s.arena = 0;
@@ -205,7 +262,7 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
     int *path = P.path + (size_t)g * P.path_cap;
 
     int kind = AZH_LEAF_NONE, leaf_node = 0, depth = 0, over = 0;
-    u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0;
+    u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0, st_cached = 0;
     u64 leaf_mover = 0, leaf_opp = 0;
 
     if (s.phase == 2) {
@@ -370,6 +427,9 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
             }
             const u32 cid = (u32)s.n_nodes;
             s.n_nodes += 1;
+            u32 known = NONE;  // a node of this tree that already carries the evaluation of this position
+            if ((P.flags & AZH_FLAG_EVAL_CACHE) && res2 == 0)
+                known = tt_lookup(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, A, pack_word0(cb), cb.o);
             if (res2 != 0) {
                 float tv = res2 == 1 ? 1.0f : -1.0f;
                 if (cb.turn == 1)
@@ -377,6 +437,21 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
                 if (lane == 0)
                     A.ni[cid] = make_uint4(0u, (u32)res2 << 16, 0u, f2u(tv));
                 kind = AZH_LEAF_TERMINAL;
+            } else if (known != NONE) {
+                // same position, same moves in the same order: take the priors and the value, no evaluation
+                const uint4 kinfo = A.ni[known];
+                const u32 nf = (u32)s.n_edges;
+                for (int j = lane; j < M2; j += WAVE) {
+                    A.ed[nf + j] = make_uint4(A.ed[kinfo.x + j].x, 0u, 0u, NONE);
+                    A.em[nf + j] = s_moves[j];
+                    A.ek[nf + j] = make_uint2(0u, 0u);
+                }
+                s.n_edges += M2;
+                if (lane == 0)
+                    A.ni[cid] = make_uint4(nf, (u32)M2, 0u, kinfo.w);
+                kind = AZH_LEAF_TERMINAL;  // "value known": backed up from node_info.w like a finished position
+                st_cached = 1;
+                st_newmoves = (u64)M2;
             } else {
                 const u32 nf = (u32)s.n_edges;
                 for (int j = lane; j < M2; j += WAVE) {
@@ -422,7 +497,8 @@ __device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
                       : lane == AZH_STAT_LEVELS ? st_levels
                       : lane == AZH_STAT_CHILDREN ? st_children
                       : lane == AZH_STAT_NEW_MOVES ? st_newmoves
-                      : lane == AZH_STAT_EDGE_OVERFLOW ? (u64)(over == 1) : 0ull;
+                      : lane == AZH_STAT_EDGE_OVERFLOW ? (u64)(over == 1)
+                      : lane == AZH_STAT_CACHE_HITS ? st_cached : 0ull;
         if (lane < NSTAT)
             add_stat(P, g, lane, inc);
     }
@@ -569,6 +645,14 @@ __device__ inline void backup_game(const EngineParams &P, int g)
         }
     }
 
+    if ((P.flags & AZH_FLAG_EVAL_CACHE) && kind == AZH_LEAF_EVAL) {
+        // the leaf now carries an evaluation: remember its value and enter it in the table
+        if (lane == 0) {
+            reinterpret_cast<u32 *>(&A.ni[s.leaf_node])[3] = f2u(P.values[g]);
+            const ulonglong2 b = A.nb[s.leaf_node];
+            tt_insert(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, b.x, b.y, (u32)s.leaf_node);
+        }
+    }
     if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_TERMINAL) {
         // step() part 4 (:449-459): flip the score at every edge on the way up.
         const float v = kind == AZH_LEAF_EVAL ? P.values[g] : u2f(A.ni[s.leaf_node].w);
@@ -850,6 +934,21 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
         st_nodes = t;
         st_edges = eb;
     }
+    if (P.flags & AZH_FLAG_EVAL_CACHE) {
+        // the kept subtree's evaluations stay usable: rebuild the table of the new arena from its nodes (all but the
+        // root, whose priors are about to get this ply's noise; finished positions carry no priors)
+        u32 *tt = tt_of(P, 1 - s.arena, g);
+        tt_clear(tt, P.tt_size);
+        __threadfence();
+        __syncthreads();
+        for (u32 n = 1u + (u32)lane; n < (u32)s.n_nodes; n += WAVE) {
+            const uint4 info = B.ni[n];
+            if ((info.y >> 16) == 0u && (info.y & 0xFFFFu) != 0u) {
+                const ulonglong2 b = B.nb[n];
+                tt_insert(tt, (u32)P.tt_size - 1u, b.x, b.y, n);
+            }
+        }
+    }
     s.arena = 1 - s.arena;
     s.ply += 1;
     __syncthreads();
@@ -1116,6 +1215,11 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.gs, G);
     rc |= dev_alloc(e, &P.force, G);
     rc |= dev_alloc(e, &P.no_emit, G);
+    P.tt_size = 1;
+    while (P.tt_size < 4 * P.node_cap)
+        P.tt_size <<= 1;
+    if (cfg->flags & AZH_FLAG_EVAL_CACHE)
+        rc |= dev_alloc(e, &P.tt, 2 * G * (size_t)P.tt_size);
     rc |= dev_alloc(e, &P.adv_list, G);
     rc |= dev_alloc(e, &P.adv_count, 1);
     rc |= dev_alloc(e, &P.path, G * P.path_cap);

@@ -253,6 +253,10 @@ def main():
                     help="tree levels per select launch and game (azh_config.select_budget; 0 = unlimited): deeper "
                          "descents park and resume next iteration, so a launch does not last as long as the deepest "
                          "line of the batch; every game still plays exactly the same search")
+    ap.add_argument("--eval-cache", action="store_true",
+                    help="AZH_FLAG_EVAL_CACHE: positions a game's search has already evaluated are not sent to the net "
+                         "again (engine.py's NNEvaluator.cache).  Off in the headline: the C++ generator evaluates every "
+                         "new node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-ceiling", action="store_true",
                     help="skip the vendor-library bf16 GEMM measured beside the roofline (context for roofline.frac)")
@@ -293,7 +297,7 @@ def main():
     conv, bn = model.random_init(args.blocks, 128, seed=1)
     sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
                            seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank), streams=args.streams,
-                           select_budget=args.select_budget)
+                           select_budget=args.select_budget, flags=link.FLAG_EVAL_CACHE if args.eval_cache else 0)
     ages = spread(sp, args, distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank))
     d, finished, dt, tm, finished_per_step = measure(sp, args, args.steps, args.warmup, group)
     steps_total, t_max, rate = distrib.aggregate(group, d["steps"], dt)
@@ -325,7 +329,7 @@ def main():
                        "step": "%d search iterations over the whole batch + one drain of the finished games"
                                % args.iters_per_step,
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
-                       "select_budget": args.select_budget,
+                       "select_budget": args.select_budget, "eval_cache": bool(args.eval_cache),
                        "setup": ("slots loaded with steady-state positions built from one complete generation of real games of "
                                  "this workload (%s, mean ply %.0f), trees grown for %d untimed iterations, then the warm-up"
                                  % (ages["source"], ages["mean_ply"], args.phase_fill)) if ages else "cold start",

@@ -155,6 +155,12 @@ enum {
     AZH_FLAG_SYMMETRY_AVG = 128,  /* every evaluation is nn_evals.evaluate (nn_evals.py:48-62): the mean over the 8
                                      dihedral symmetries of the board, logits brought back spatially (move-type
                                      layers not permuted, as the reference), values averaged; 8x the tower work */
+    AZH_FLAG_EVAL_CACHE = 256,    /* engine.py's NNEvaluator.cache (engine.py:127-234) for the device loop: a position this
+                                     game's search has already evaluated (a transposition, a re-visited position: about
+                                     a quarter of the leaves at 400 sims/move) takes its priors and value from the node
+                                     that carries them instead of going to the net again.  Off by default: the C++
+                                     generator evaluates every new node.  The net being deterministic, the trees are the
+                                     ones the uncached search builds; AZH_STAT_NN_EVALS falls, AZH_STAT_CACHE_HITS counts */
     AZH_FLAG_ONE_RANDOM_MOVE = 64 /* the ONE_RANDOM_MOVE build of the client (cpp/self_play_client.cpp:515-552):
                                      per game one ply in 0..119 plays a uniformly random legal move, every later
                                      ply the most visited move; the entry gains "random_ply" (train.py:47-49) */
@@ -168,7 +174,7 @@ typedef struct {
 enum {
     AZH_STAT_STEPS = 0, AZH_STAT_NN_EVALS, AZH_STAT_LEVELS, AZH_STAT_CHILDREN, AZH_STAT_NEW_MOVES,
     AZH_STAT_PLIES, AZH_STAT_GAMES, AZH_STAT_DROPPED, AZH_STAT_EDGE_OVERFLOW, AZH_STAT_REROOT_NODES,
-    AZH_STAT_REROOT_EDGES, AZH_STAT_RING_OVERFLOW
+    AZH_STAT_REROOT_EDGES, AZH_STAT_RING_OVERFLOW, AZH_STAT_CACHE_HITS
 };
 
 typedef struct {

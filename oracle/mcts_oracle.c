@@ -42,6 +42,8 @@ struct orc_engine {
     blob *done_head, *done_tail;
     int done_count;
     int32_t *no_emit;  /* [G] the slot's current game was started by orc_engine_set_positions: counted, not written */
+    uint32_t *tt;      /* ORC_FLAG_EVAL_CACHE: [2][G][tt_size] open-addressed table of evaluated nodes, keyed by the board */
+    int tt_size;
 };
 
 static inline uint64_t *NB(const orc_engine *e, int a, int g) { return e->node_board + ((size_t)(a * e->G + g) * e->node_cap) * 2; }
@@ -63,6 +65,47 @@ static void pack(const orc_pos *p, uint64_t *b)
 {
     b[0] = p->pieces[0] | ((uint64_t)p->turn << 63);
     b[1] = p->pieces[1];
+}
+
+/* ---- evaluation cache (ORC_FLAG_EVAL_CACHE): engine.py's NNEvaluator.cache (engine.py:127-234) per game.  A position
+ * the game's search has already evaluated takes its priors and value from the node that carries them.  Same hash and
+ * same open addressing as the HIP engine; the engine enters several nodes at once when it rebuilds the table after a
+ * move, so two nodes with the same board may sit in a different order there — they carry the same evaluation. */
+static inline uint32_t *TT(const orc_engine *e, int a, int g) { return e->tt + ((size_t)a * e->G + g) * (size_t)e->tt_size; }
+
+static uint32_t tt_hash(uint64_t w0, uint64_t w1, uint32_t mask)
+{
+    uint64_t k = (w0 * 0x9E3779B97F4A7C15ULL) ^ ((w1 + 0x7F4A7C15ULL) * 0xC2B2AE3D27D4EB4FULL);
+    return (uint32_t)(k >> 40) & mask;
+}
+
+static uint32_t tt_lookup(const orc_engine *e, int a, int g, uint64_t w0, uint64_t w1)
+{
+    const uint32_t *tt = TT(e, a, g);
+    uint32_t mask = (uint32_t)e->tt_size - 1u;
+    const uint64_t *nb = NB(e, a, g);
+    uint32_t slot = tt_hash(w0, w1, mask);
+    for (int tries = 0; tries < 64 && tt[slot] != NONE; tries++, slot = (slot + 1) & mask)
+        if (nb[2 * (size_t)tt[slot]] == w0 && nb[2 * (size_t)tt[slot] + 1] == w1)
+            return tt[slot];
+    return NONE;
+}
+
+static void tt_insert(orc_engine *e, int a, int g, uint32_t id)
+{
+    uint32_t *tt = TT(e, a, g);
+    uint32_t mask = (uint32_t)e->tt_size - 1u;
+    const uint64_t *b = NB(e, a, g) + 2 * (size_t)id;
+    uint32_t slot = tt_hash(b[0], b[1], mask);
+    while (tt[slot] != NONE)
+        slot = (slot + 1) & mask;
+    tt[slot] = id;
+}
+
+static void tt_clear(orc_engine *e, int a, int g)
+{
+    if (e->cfg.flags & ORC_FLAG_EVAL_CACHE)
+        memset(TT(e, a, g), 0xFF, sizeof(uint32_t) * (size_t)e->tt_size);
 }
 
 /* 64-lane emulation: sum v[0..n) as lane-striped partials + xor butterfly with offsets
@@ -144,6 +187,7 @@ static void init_game(orc_engine *e, int g, uint32_t uid)
     p.ply = 0;
     make_node(e, g, 0, 0, &p, NULL);
     s->n_nodes = 1;
+    tt_clear(e, 0, g);
 }
 
 orc_engine *orc_engine_create(const orc_config *cfg)
@@ -165,6 +209,11 @@ orc_engine *orc_engine_create(const orc_config *cfg)
     e->edge_move = (uint16_t *)calloc(2 * G * e->edge_cap, sizeof(uint16_t));
     e->rec = (uint8_t *)calloc(G * cfg->max_plies, REC_STRIDE);
     e->stats = (uint64_t *)calloc(G * ORC_STAT_COUNT, sizeof(uint64_t));
+    e->tt_size = 1;
+    while (e->tt_size < 4 * e->node_cap)
+        e->tt_size <<= 1;
+    if (cfg->flags & ORC_FLAG_EVAL_CACHE)
+        e->tt = (uint32_t *)malloc(sizeof(uint32_t) * 2 * G * (size_t)e->tt_size);
     for (int g = 0; g < e->G; g++)
         init_game(e, g, (uint32_t)g);
     return e;
@@ -175,7 +224,7 @@ void orc_engine_destroy(orc_engine *e)
     if (!e) return;
     while (e->done_head) { blob *n = e->done_head->next; free(e->done_head); e->done_head = n; }
     free(e->gs); free(e->force); free(e->path); free(e->node_board); free(e->node_info);
-    free(e->edge); free(e->edge_move); free(e->rec); free(e->stats); free(e->no_emit); free(e);
+    free(e->edge); free(e->edge_move); free(e->rec); free(e->stats); free(e->no_emit); free(e->tt); free(e);
 }
 
 int orc_engine_node_cap(const orc_engine *e) { return e->node_cap; }
@@ -195,6 +244,7 @@ void orc_engine_set_positions(orc_engine *e, const uint64_t *boards, const int32
         unpack(e, boards + 2 * (size_t)g, &p);
         make_node(e, g, 0, 0, &p, NULL);
         s->n_nodes = 1;
+        tt_clear(e, 0, g);
     }
 }
 
@@ -307,8 +357,22 @@ static void select_game(orc_engine *e, int g)
         int result2 = (int)(ni[4 * cid + 1] >> 16);
         s->leaf_node = (int)cid;
         s->path_len = depth;
+        uint32_t known = NONE;
+        if ((e->cfg.flags & ORC_FLAG_EVAL_CACHE) && result2 == 0) {
+            const uint64_t *cb = NB(e, a, g) + 2 * (size_t)cid;
+            known = tt_lookup(e, a, g, cb[0], cb[1]);
+        }
         if (result2 != 0) {
             s->leaf_kind = ORC_LEAF_TERMINAL;
+        } else if (known != NONE) {
+            /* this game's search has evaluated the position before: same moves in the same order, take the priors and
+             * the value; backed up from node_info[3] like a finished position, no evaluation */
+            uint32_t kf = ni[4 * known + 0], nf = ni[4 * cid + 0];
+            for (int j = 0; j < M2; j++)
+                ed[4 * (size_t)(nf + j) + 0] = ed[4 * (size_t)(kf + j) + 0];
+            ni[4 * cid + 3] = ni[4 * known + 3];
+            s->leaf_kind = ORC_LEAF_TERMINAL;
+            st[ORC_STAT_CACHE_HITS]++;
         } else {
             s->leaf_kind = ORC_LEAF_EVAL;
             st[ORC_STAT_NN_EVALS]++;
@@ -620,6 +684,13 @@ static void advance_game(orc_engine *e, int g)
         st[ORC_STAT_REROOT_NODES] += t;
         st[ORC_STAT_REROOT_EDGES] += eb;
     }
+    if (e->cfg.flags & ORC_FLAG_EVAL_CACHE) {
+        /* the kept subtree's evaluations stay usable (all nodes but the root, whose priors get this ply's noise) */
+        tt_clear(e, b, g);
+        for (uint32_t n = 1; n < (uint32_t)s->n_nodes; n++)
+            if ((ni2[4 * n + 1] >> 16) == 0 && (ni2[4 * n + 1] & 0xFFFFu) != 0)
+                tt_insert(e, b, g, n);
+    }
     s->ply += 1;
     e->force[g] = 0;
     int result = (int)(ni2[1] >> 16);
@@ -658,6 +729,10 @@ void orc_engine_backup(orc_engine *e, const float *logits, const float *values)
             break;
         case ORC_LEAF_EVAL:
             apply_priors(e, g, lg, 0);
+            if (e->cfg.flags & ORC_FLAG_EVAL_CACHE) {
+                NI(e, s->arena, g)[4 * (size_t)s->leaf_node + 3] = orc_f2u(values[g]);
+                tt_insert(e, s->arena, g, (uint32_t)s->leaf_node);
+            }
             backup_path(e, g, values[g]);
             break;
         case ORC_LEAF_TERMINAL: {

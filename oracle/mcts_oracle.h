@@ -45,7 +45,8 @@ typedef struct {
 enum {
     ORC_FLAG_NO_REUSE = 1, ORC_FLAG_TIE_FIRST = 2, ORC_FLAG_PY_POSTERIOR = 4, ORC_FLAG_SAMPLE_POW5 = 8,
     ORC_FLAG_KEEP_UNFINISHED = 16, ORC_FLAG_TWO_NETS = 32, ORC_FLAG_ARENA = 63,
-    ORC_FLAG_ONE_RANDOM_MOVE = 64 /* the ONE_RANDOM_MOVE build of the client (cpp/self_play_client.cpp:515-552) */
+    ORC_FLAG_ONE_RANDOM_MOVE = 64, /* the ONE_RANDOM_MOVE build of the client (cpp/self_play_client.cpp:515-552) */
+    ORC_FLAG_EVAL_CACHE = 256      /* engine.py's NNEvaluator.cache (engine.py:127-234), per game: mirror of AZH_FLAG_EVAL_CACHE */
 };
 
 enum { ORC_LEAF_NONE = 0, ORC_LEAF_EVAL = 1, ORC_LEAF_TERMINAL = 2, ORC_LEAF_ROOT = 3, ORC_LEAF_DESCENT = 4 };
@@ -72,6 +73,7 @@ enum {
     ORC_STAT_EDGE_OVERFLOW,
     ORC_STAT_REROOT_NODES,
     ORC_STAT_REROOT_EDGES,
+    ORC_STAT_CACHE_HITS,     /* expansions served by the evaluation cache */
     ORC_STAT_COUNT = 16
 };
 

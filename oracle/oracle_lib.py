@@ -12,12 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 
 STAT_NAMES = ["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
-              "edge_overflow", "reroot_nodes", "reroot_edges"]
+              "edge_overflow", "reroot_nodes", "reroot_edges", "cache_hits"]
 STAT_COUNT = 16
 LEAF_NONE, LEAF_EVAL, LEAF_TERMINAL, LEAF_ROOT, LEAF_DESCENT = 0, 1, 2, 3, 4
 FLAG_NO_REUSE, FLAG_TIE_FIRST, FLAG_PY_POSTERIOR, FLAG_SAMPLE_POW5, FLAG_KEEP_UNFINISHED, FLAG_TWO_NETS = 1, 2, 4, 8, 16, 32
 FLAG_ARENA = 63
 FLAG_ONE_RANDOM_MOVE = 64
+FLAG_EVAL_CACHE = 256
 
 
 class Pos(ctypes.Structure):

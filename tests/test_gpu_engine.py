@@ -388,3 +388,37 @@ def test_loaded_positions_hook_matches_oracle():
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]   # complete games from the start position
     with pytest.raises(link.AzhError):
         ge2.set_positions(boards, np.full(24, 200, np.int32))       # ply beyond max_plies
+
+
+def test_evaluation_cache_matches_oracle_and_saves_evaluations():
+    """AZH_FLAG_EVAL_CACHE in the device-resident loop against the oracle's same rule, f32 tower on both sides (so an
+    evaluation taken from the cache is bit for bit what the net would return): states, trees, game lines and counters;
+    and against the uncached engine: the same games, fewer evaluations."""
+    conv, bn = model.random_init(2, 128, seed=7)
+    net = link.Net(conv, bn)
+    oe, ge = make_pair(games=256, visits=60, max_plies=400, seed=31, select_budget=48, flags=orc.FLAG_EVAL_CACHE)
+    assert link.FLAG_EVAL_CACHE == orc.FLAG_EVAL_CACHE
+    lines = []
+    for c in range(5):
+        ge.run(net, 300, link.DTYPE_F32)
+        _oracle_follow(oe, net, oe.cfg.blockers, 300)
+        ge.sync()
+        compare_all(oe, ge, range(256))
+        o_chunk = sorted(oe.pop_games(), key=lambda r: r["uid"])
+        g_chunk = ge.drain_json()
+        assert [json.loads(l) for l in g_chunk] == [r["entry"] for r in o_chunk]
+        lines += g_chunk
+    so, sg = oe.stats(), ge.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    # (2 % here: 60 sims/move from the opening; about a quarter at 400 sims/move in mid-game, tools/leaf_duplicates.py)
+    assert sg["cache_hits"] > 0.01 * sg["nn_evals"], (sg["cache_hits"], sg["nn_evals"])
+    # the uncached engine plays the same games (same seeds), with more evaluations
+    _, plain = make_pair(games=256, visits=60, max_plies=400, seed=31, select_budget=48)
+    plain_lines = []
+    for c in range(5):
+        plain.run(net, 300, link.DTYPE_F32)
+        plain_lines += plain.drain_json()
+    sp = plain.stats()
+    assert plain_lines == lines and sp["steps"] == sg["steps"] and sp["plies"] == sg["plies"]
+    assert sp["nn_evals"] == sg["nn_evals"] + sg["cache_hits"]

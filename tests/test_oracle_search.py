@@ -178,3 +178,32 @@ def test_root_noise_is_dirichlet_and_moves_follow_the_visits():
     obs = np.array([played.get(k, 0) for k in keys], dtype=np.float64)
     exp = np.array([expect[k] for k in keys])
     assert stats.chisquare(obs, exp).pvalue > 1e-3
+
+
+def test_evaluation_cache_changes_no_tree():
+    """ORC_FLAG_EVAL_CACHE (engine.py's NNEvaluator.cache, per game): with a deterministic evaluator the cached search
+    builds exactly the trees of the uncached one — every board, move, prior, visit count and score, iteration for
+    iteration — while a good share of the expansions never reaches the evaluator."""
+    from tests.helpers import synthetic_evals
+    a = orc.Engine(orc.make_config(games=12, visits=120, seed=5))
+    b = orc.Engine(orc.make_config(games=12, visits=120, seed=5, flags=orc.FLAG_EVAL_CACHE))
+    asked_a = asked_b = 0
+    for it in range(900):
+        na, need_a = a.select()
+        nb, need_b = b.select()
+        asked_a += na
+        asked_b += nb
+        assert ((need_b == 0) | (need_a == need_b)).all()          # the cache only ever removes evaluations
+        la, lb = a.leaf_boards(), b.leaf_boards()
+        assert (la == lb).all()
+        a.backup(*synthetic_evals(la))
+        b.backup(*synthetic_evals(lb))
+        if it % 60 == 0 or it == 899:
+            for g in range(12):
+                ta, tb = a.tree(g), b.tree(g)
+                assert (ta[0] == tb[0]).all() and (ta[2] == tb[2]).all() and (ta[3] == tb[3]).all()
+                assert (ta[1][:, :3] == tb[1][:, :3]).all()            # node_info[3] also keeps the value when caching
+    sa, sb = a.stats(), b.stats()
+    assert sa["steps"] == sb["steps"] and sa["plies"] == sb["plies"] >= 60
+    assert sb["cache_hits"] > 0 and sb["nn_evals"] + sb["cache_hits"] == sa["nn_evals"] and asked_b < asked_a
+    # (few with this peaked synthetic evaluator; about a quarter of the expansions with a real net: tools/leaf_duplicates.py)
