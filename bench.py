@@ -177,19 +177,21 @@ def spread(sp, args, seed):
     return {"mean_ply": float(plies[pick].mean()), "source": SNAPSHOT}
 
 
-def target_leg(conv, bn, args, games=16384, steps=2, warmup=1):
-    """BASELINE.json's north-star operating point (>= 10k concurrent games on one GPU, 400 sims/move) measured
-    the same way as the headline, reported beside it (never as `value`)."""
+def target_leg(conv, bn, args, games=16384, steps=2, warmup=1, flags=0):
+    """Another operating point measured the same way as the headline and reported beside it (never as `value`):
+    BASELINE.json's north-star point (>= 10k concurrent games on one GPU, 400 sims/move), or the headline workload with the
+    evaluation cache on."""
     from ataxxzero_amd import model, selfplay
     sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=args.dtype, seed=selfplay.DEFAULT_SEED + 77,
-                           select_budget=args.select_budget)
+                           select_budget=args.select_budget, flags=flags)
     try:
         spread(sp, args, selfplay.DEFAULT_SEED + 77)
         d, finished, dt, tm, _ = measure(sp, args, steps, warmup)
         it = max(tm["iterations"], 1)
         iters = steps * args.iters_per_step
         tf = d["nn_evals"] / float(iters) * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] / it * 1e-3) / 1e12
-        return {"games": games, "node_evals_per_s": d["steps"] / dt, "games_per_s": d["games"] / dt,
+        return {"games": games, "node_evals_per_s": d["steps"] / dt, "nn_evals_per_s": d["nn_evals"] / dt,
+                "cache_hits_per_s": d.get("cache_hits", 0) / dt, "plies_per_s": d["plies"] / dt, "games_per_s": d["games"] / dt,
                 "ms_per_iteration": 1e3 * dt / iters, "steps": steps,
                 "tower_ms_per_launch": tm["net_ms"] / it, "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[args.dtype],
                 "tree_ms_per_iteration": (tm["select_ms"] + tm["backup_ms"]) / it}
@@ -358,6 +360,11 @@ def main():
         sp.close()
         if group.world == 1 and not args.no_target_leg and args.streams == 1:
             out["target_10k_games"] = target_leg(conv, bn, args)
+            if not args.eval_cache:
+                # the same workload with AZH_FLAG_EVAL_CACHE: MCTS steps/s and games/s rise, net evaluations/s do not (the
+                # headline keeps the C++ generator's rule: every new node goes to the net)
+                out["with_eval_cache"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2,
+                                                    flags=link.FLAG_EVAL_CACHE)
         if group.world == 1 and not args.no_gemm_ceiling:
             out["roofline"]["vendor_gemm_on_this_box"] = vendor_gemm_ceiling()
         if group.world == 1 and not args.no_cpu_baseline:
