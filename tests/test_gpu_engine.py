@@ -390,6 +390,27 @@ def test_loaded_positions_hook_matches_oracle():
         ge2.set_positions(boards, np.full(24, 200, np.int32))       # ply beyond max_plies
 
 
+def test_evaluation_cache_through_game_turnover_matches_oracle():
+    # many plies, finished and cut games, slots restarting: the table is cleared / rebuilt at every one of those events
+    conv, bn = model.random_init(2, 128, seed=7)
+    net = link.Net(conv, bn)
+    oe, ge = make_pair(games=384, visits=12, max_plies=90, seed=99, select_budget=6, flags=orc.FLAG_EVAL_CACHE)
+    written = 0
+    for c in range(10):
+        ge.run(net, 250, link.DTYPE_F32)
+        _oracle_follow(oe, net, oe.cfg.blockers, 250)
+        ge.sync()
+        compare_all(oe, ge, range(384))
+        o_chunk = sorted(oe.pop_games(), key=lambda r: r["uid"])
+        g_chunk = ge.drain_json()
+        assert [json.loads(l) for l in g_chunk] == [r["entry"] for r in o_chunk]
+        written += len(g_chunk)
+    so, sg = oe.stats(), ge.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    assert written > 40 and so["dropped"] > 0 and so["cache_hits"] > 0 and so["reroot_nodes"] > so["plies"]
+
+
 def test_evaluation_cache_matches_oracle_and_saves_evaluations():
     """AZH_FLAG_EVAL_CACHE in the device-resident loop against the oracle's same rule, f32 tower on both sides (so an
     evaluation taken from the cache is bit for bit what the net would return): states, trees, game lines and counters;
