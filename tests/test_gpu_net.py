@@ -145,3 +145,23 @@ def test_full_size_launch_is_position_independent(dtype):
             assert np.abs(p[lo:lo + n] - p[:n]).max() <= tol and np.abs(v[lo:lo + n] - v[:n]).max() <= tol
     small_p, small_v = net.forward(base[:37], BLOCK4_MASK, dtype)
     assert (small_p == p[:37]).all() and (small_v == v[:37]).all()
+
+
+def test_f32_tower_agrees_with_pytorch_conv_and_batch_norm():
+    """A third-party arithmetic beside the numpy restatement: the same weights in torch.nn (Conv2d / BatchNorm2d in
+    eval mode / Linear, float64 on the CPU, NCHW) and the HIP f32 tower must agree to 1e-5 on identical boards.  The
+    reference's own arithmetic (TensorFlow 1) is not available; two independent implementations of its documented
+    semantics are the closest check there is."""
+    import torch
+    from ataxxzero_amd import training
+    conv, bn = model.random_init(12, 128, seed=3, perturb_bn=True)
+    tnet = training.Network(12, 128).double()
+    tnet.load_numpy(conv, bn)
+    tnet.eval()
+    lb = sample_leaf_boards(24, 11, BLOCK4_MASK)
+    feats = net_oracle.features_from_leaf_boards(lb, BLOCK4_MASK, np.float64)
+    with torch.no_grad():
+        tp, tv = tnet(torch.from_numpy(feats).permute(0, 3, 1, 2))
+    p, v = link.Net(conv, bn).forward(lb, BLOCK4_MASK, link.DTYPE_F32)
+    assert np.abs(p - tp.numpy()).max() <= 1e-5 and np.abs(v - tv.numpy()).max() <= 1e-5
+    assert np.abs(tp.numpy()).max() > 1e-3
