@@ -280,14 +280,16 @@ def test_generate_games_supervised_with_own_uai_engine_as_teacher(tmp_path):
 
 
 def test_accelerated_generate_games_extension_flags(tmp_path):
-    """--one-random-move (the client's ONE_RANDOM_MOVE build as a switch), --select-budget, --streams 2, --max-seconds."""
+    """--one-random-move (the client's ONE_RANDOM_MOVE build as a switch), --select-budget, --streams 2, --eval-cache,
+    --emit-order finish, --seed, --max-seconds."""
     conv, bn = model.random_init(1, 128, seed=5)
     net_path = str(tmp_path / "model-002.npy")
     model.save_model(net_path, conv, bn)
     games_path = str(tmp_path / "model-002-0.json")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "accelerated_generate_games.py"), "--network", net_path,
                           "--output-games", games_path, "--visits", "6", "--buffer-size", "48", "--one-random-move",
-                          "--select-budget", "3", "--streams", "2", "--max-seconds", "12"],
+                          "--select-budget", "3", "--streams", "2", "--eval-cache", "--emit-order", "finish", "--seed", "5",
+                          "--max-seconds", "12"],
                          cwd=ROOT, capture_output=True, timeout=240)
     assert res.returncode == 0, res.stdout.decode()[-2000:] + res.stderr.decode()[-2000:]
     lines = [l for l in open(games_path) if l.strip()]
