@@ -589,6 +589,15 @@ __global__ __launch_bounds__(64 * (FT / 32), WPS) void k_tower(TowerArgs A)
 constexpr int RING2 = AZH_RING2;
 #ifndef AZH_SETPRIO
 #define AZH_SETPRIO 0
+#endif
+#ifndef AZH_PKRELU
+#define AZH_PKRELU 1   /* +1.0 % at 16 K boards, +~1 % at 3.6 K (profiles/round2_tower_variants.txt) */
+#endif
+#ifndef AZH_UNIFORM_WAVE
+#define AZH_UNIFORM_WAVE 1
+#endif
+#ifndef AZH_BUFFER_A
+#define AZH_BUFFER_A 1   /* with AZH_UNIFORM_WAVE: another 0.6 % at 16 K boards, ~1 % at 3.6 K (same profile) */
 #endif  // A-fragment ring depth of variant 2 (steps of prefetch distance)
 
 template <int DT> struct Mfma16;
@@ -657,6 +666,7 @@ __device__ constexpr bool skip_pair(int ct, int inner) { return (ct == 0 && inne
 
 template <int DT, int KS, int CHF, bool STAMP>
 __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, bool skip,
+                                   __amdgpu_buffer_rsrc_t wrsrc, const void *wbase0,
                                    const typename Traits<DT>::afrag *__restrict__ wp,
                                    typename Traits<DT>::afrag (&a)[RING2][4], f32x16 &sh, const float *__restrict__ shift_next,
                                    const int (&vmask)[Geo2::TPW], const int (&cellv)[Geo2::TPW], int wave, int lane,
@@ -713,14 +723,28 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     };
 
     // A fragments of packed step s = tap * KS + ks: [s][oc tile 8][lane][8 elements]; this wave reads tiles 4*oh .. 4*oh+3
-    const char *wbase = reinterpret_cast<const char *>(wp) + oh * 4096;
     const unsigned lane_off = (unsigned)(lane * sizeof(afrag));
+#if AZH_BUFFER_A
+    // buffer loads: resource (base of the packed weights) and the step's offset in scalar registers, the lane's 16-B
+    // slot in one VGPR, the tile in the immediate — no 64-bit vector address arithmetic in the k-loop
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const unsigned wbyte = (unsigned)(reinterpret_cast<const char *>(wp) - reinterpret_cast<const char *>(wbase0)) +
+                           (unsigned)__builtin_amdgcn_readfirstlane(oh * 4096);
+    auto load_a = [&](afrag (&dst)[4], int step) {
+        const unsigned soff = wbyte + (unsigned)step * 8192u;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            dst[t] = __builtin_bit_cast(afrag, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + t * 1024, soff, 0));
+    };
+#else
+    const char *wbase = reinterpret_cast<const char *>(wp) + oh * 4096;
     auto load_a = [&](afrag (&dst)[4], int step) {
         const char *p = wbase + (size_t)step * 8192;
 #pragma unroll
         for (int t = 0; t < 4; t++)
             dst[t] = *reinterpret_cast<const afrag *>(p + t * 1024 + lane_off);
     };
+#endif
     // (row o, inner i) -> tap = 3 dxi + dyi
     auto tap_of = [&](int o, int i) { return CHF == 0 ? 3 * o + i : 3 * i + o; };
     // packed step of walk position (row o, step j of the row); positions past the layer continue into the next
@@ -810,6 +834,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             tap_row(d, IC<(ROW * d) & 1>(), IC<(ROW * d) % RING2>());
         });
     } else {
+#pragma nounroll
         for (int o = 0; o < 3; o++)
             tap_row(o, IC<0>(), IC<0>());
     }
@@ -840,15 +865,26 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     v[i] = acc[t][ct][i];
+#if !AZH_PKRELU
                     v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+#endif
                 }
                 f32x2 lo, hi;
                 lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
                 typedef typename Tr::pair pair;
                 const pair plo = __builtin_convertvector(lo, pair), phi = __builtin_convertvector(hi, pair);
                 uint2 packed;
+#if AZH_PKRELU
+                // relu after the conversion, on the packed pair: a negative bf16 / f16 is a negative int16, so one packed
+                // integer max with 0 clears it (conversion and relu commute: both are monotone and keep the sign)
+                typedef short short2v __attribute__((ext_vector_type(2)));
+                const short2v zero2 = {0, 0};
+                packed.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, plo), zero2));
+                packed.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, phi), zero2));
+#else
                 packed.x = __builtin_bit_cast(unsigned, plo);
                 packed.y = __builtin_bit_cast(unsigned, phi);
+#endif
                 *reinterpret_cast<uint2 *>(lds + G::ch_off(G::real_slot(out_img, cell), 64 * oh + 16 * t + 4 * kg)) = packed;
             }
         }
@@ -884,6 +920,8 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
         }
     }
     const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w2);
+    // buffer resource over the packed weights (raw 32-bit data, no bounds smaller than the stream; gfx94x/gfx950 word 3)
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.conv_w2), 0, 0x7FFFFFFF, 0x00020000);
     const size_t l0 = (size_t)9 * G::KS_IN * 8 * 64, lf = (size_t)9 * G::KS_FULL * 8 * 64;
     const int oh = wave >> 1, kg = lane >> 4;
     afrag aring[RING2][4];
@@ -904,18 +942,18 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
             sh[4 * t + i] = t4[i];
     }
     if constexpr (STAMP) st[1] = stamp_now();
-    conv_layer2<DT, G::KS_IN, CHF, STAMP>(smem, 0, 1, false, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
+    conv_layer2<DT, G::KS_IN, CHF, STAMP>(smem, 0, 1, false, wrsrc, A.conv_w2, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
     __syncthreads();
     if constexpr (STAMP) st[7] = stamp_now();
     wp += l0;
     for (int b = 0; b < A.blocks; b++) {
         const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 1, 0, false, wp, aring, sh, t1 + F, vmask, cellv, wave, lane,
+        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 1, 0, false, wrsrc, A.conv_w2, wp, aring, sh, t1 + F, vmask, cellv, wave, lane,
                                                 st + 8 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
         wp += lf;
-        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 0, 1, true, wp, aring, sh, t1 + 2 * F, vmask, cellv, wave, lane,
+        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 0, 1, true, wrsrc, A.conv_w2, wp, aring, sh, t1 + 2 * F, vmask, cellv, wave, lane,
                                                 st + 12 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
@@ -930,7 +968,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     typedef Geo2 G;
     typedef typename Tr::afrag afrag;
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+#if AZH_UNIFORM_WAVE
+    // the wave index is the same in all 64 lanes: say so, and everything derived from it (the weight stream's base
+    // address above all) lives in scalar registers instead of being recomputed per lane
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
+    const int wave = tid >> 6;
+#endif
     const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
     const int tile0 = blockIdx.x * G::BOARDS;
     if (tile0 >= n)

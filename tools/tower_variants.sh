@@ -35,3 +35,5 @@ for round in 1 2 3; do
     echo "round $round [${names[$k]}]: $(AZH_LIB=$R/${libs[$k]} python tools/net_bench.py ${N:-3600 16384} | tr '\n' ' ')"
   done
 done
+# optional: run the net tests against the first variant (CHECK=1)
+if [ -n "$CHECK" ]; then AZH_LIB=$R/gpurun_out/variant_1/lib.so python -m pytest tests/test_gpu_net.py -q -m gpu 2>&1 | tail -2; fi
