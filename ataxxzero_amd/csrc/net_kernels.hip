@@ -756,7 +756,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         }
         return o < 3 ? tap_of(o, j / KS) * KS + j % KS : TOTAL + j;
     };
-    // byte offsets of this lane's B fragments for the tap at (row o, inner i); skipped pairs are left alone
+    // byte offsets of this lane's B fragments for the tap at (row o, inner i); skipped pairs are left alone.
     auto rows_for = [&](int o, auto i_tag, int (&dst)[TPW]) {
         constexpr int i = decltype(i_tag)::value;
         const int tap = tap_of(o, i);
