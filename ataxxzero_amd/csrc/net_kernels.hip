@@ -596,6 +596,9 @@ constexpr int RING2 = AZH_RING2;
 #ifndef AZH_UNIFORM_WAVE
 #define AZH_UNIFORM_WAVE 1
 #endif
+#ifndef AZH_FIRSTC
+#define AZH_FIRSTC 1   /* +0.9 % at 16 K boards, +1.0 % at 3.6 K (profiles/round2_tower_variants.txt, call 5) */
+#endif
 #ifndef AZH_BUFFER_A
 #define AZH_BUFFER_A 1   /* with AZH_UNIFORM_WAVE: another 0.6 % at 16 K boards, ~1 % at 3.6 K (same profile) */
 #endif  // A-fragment ring depth of variant 2 (steps of prefetch distance)
@@ -684,15 +687,22 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     const int oh = wave >> 1;
     // accumulators [A tile][cell tile], started at the batch-norm shift (+ residual input)
     f32x4 acc[4][TPW];
+    f32x4 shq[4];  // the shift of this wave's four channel quads
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        f32x4 init;
+    for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            init[i] = sh[4 * t + i];
+            shq[t][i] = sh[4 * t + i];
+    // Without a residual input the accumulators are not initialised at all: the first MFMA of every (A tile, cell tile)
+    // takes the shift as its C operand and writes the accumulator (80 register copies per layer saved); with one they
+    // start at shift + residual input.
+    const bool first_c = AZH_FIRSTC && !skip;
+    if (!first_c) {
 #pragma unroll
-        for (int ct = 0; ct < TPW; ct++)
-            acc[t][ct] = init;
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int ct = 0; ct < TPW; ct++)
+                acc[t][ct] = shq[t];
     }
     if (skip) {
         typename Tr::quad sk[4][TPW];
@@ -781,9 +791,10 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     afrag b[2][TPW];
     int cur[TPW], nxt[TPW];
     // one row of three taps = 3 KS steps, straight-line: step j consumes inner tap j / KS, k-step j % KS
-    auto tap_row = [&](int o, auto par0_tag, auto ring0_tag) {
+    auto tap_row = [&](int o, auto par0_tag, auto ring0_tag, auto first_tag) {
         constexpr int par0 = decltype(par0_tag)::value;    // B buffer parity of the row's first step
         constexpr int ring0 = decltype(ring0_tag)::value;  // A ring slot of the row's first step
+        constexpr bool FIRST = decltype(first_tag)::value != 0;  // the layer's first row, accumulators not initialised
         static_for<0, ROW>([&](auto j_tag) {
             constexpr int j = decltype(j_tag)::value;
             constexpr int i = j / KS, ks = j % KS;
@@ -808,8 +819,11 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             for (int t = 0; t < 4; t++)
                 static_for<0, TPW>([&](auto ct_tag) {
                     constexpr int ct = decltype(ct_tag)::value;
-                    if constexpr (!skip_pair(ct, i))
-                        acc[t][ct] = Mfma16<DT>::mfma(a[rs][t], b[par][ct], acc[t][ct]);
+                    if constexpr (!skip_pair(ct, i)) {
+                        // the first step this cell tile takes part in (tile 0 sits out inner tap 0)
+                        constexpr bool opens = FIRST && j == (skip_pair(ct, 0) ? KS : 0);
+                        acc[t][ct] = Mfma16<DT>::mfma(a[rs][t], b[par][ct], opens ? shq[t] : acc[t][ct]);
+                    }
                 });
 #if AZH_SETPRIO
             __builtin_amdgcn_s_setprio(0);
@@ -831,12 +845,17 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     if constexpr (ROW % 2 != 0 || ROW % RING2 != 0) {
         static_for<0, 3>([&](auto d_tag) {
             constexpr int d = decltype(d_tag)::value;
-            tap_row(d, IC<(ROW * d) & 1>(), IC<(ROW * d) % RING2>());
+            if (d == 0 && first_c)
+                tap_row(d, IC<(ROW * d) & 1>(), IC<(ROW * d) % RING2>(), IC<1>());
+            else
+                tap_row(d, IC<(ROW * d) & 1>(), IC<(ROW * d) % RING2>(), IC<0>());
         });
     } else {
+        if (first_c)
+            tap_row(0, IC<0>(), IC<0>(), IC<1>());
 #pragma nounroll
-        for (int o = 0; o < 3; o++)
-            tap_row(o, IC<0>(), IC<0>());
+        for (int o = first_c ? 1 : 0; o < 3; o++)
+            tap_row(o, IC<0>(), IC<0>(), IC<0>());
     }
     if constexpr (STAMP) st[1] = stamp_now();
     fetch_shift();
