@@ -78,6 +78,27 @@ def test_bench_py_starts_its_own_ranks_and_aggregates():
     assert out["seeds"] == [20260101, 20260102]
 
 
+def test_bench_py_under_the_launcher_the_driver_uses():
+    """The round-end scaling run starts bench.py as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: the ranks read RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* from the launcher and must not start ranks of their own; rank 0 alone prints the line."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest"],
+                         env=env, capture_output=True, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["units_total"] == 3000.0 and out["t_max"] == 2.0
+    assert out["seeds"] == [20260101, 20260102]
+
+
 def test_bench_py_fails_fast_when_a_rank_dies():
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
