@@ -18,7 +18,10 @@ class Group:
         self.rank, self.local_rank, self.world = world()
         self.dist = None
         self.device = None
-        if self.world > 1:
+        self.backend = None
+        # AZH_DIST_FORCE=1: build the process group even for one rank, to rehearse the N > 1 order of initialisation
+        # (torch's HIP runtime and RCCL first, then this package's library) on a one-GPU box
+        if self.world > 1 or os.environ.get("AZH_DIST_FORCE"):
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -26,6 +29,7 @@ class Group:
             if backend is None:
                 # AZH_DIST_BACKEND=gloo: rehearse several ranks on one GPU (RCCL refuses duplicate devices)
                 backend = os.environ.get("AZH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            self.backend = backend
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)

@@ -336,7 +336,8 @@ def main():
                                  "this workload (%s, mean ply %.0f), trees grown for %d untimed iterations, then the warm-up"
                                  % (ages["source"], ages["mean_ply"], args.phase_fill)) if ages else "cold start",
                        "net": "%dx128" % args.blocks,
-                       "parallelism": "%d independent game shards, no collective" % group.world},
+                       "parallelism": "%d independent game shards, no collective" % group.world,
+                       "timing_barrier_backend": group.backend},
             "ms_per_iteration": 1e3 * t_max / iters,
             "nn_evals_per_s": evals_total / t_max, "plies_per_s": plies_total / t_max,
             "games_per_s": games_total / t_max,    # games finished (result 1 or 2) in the timed region, counted on the device

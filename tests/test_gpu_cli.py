@@ -347,3 +347,20 @@ def test_bench_py_two_ranks_on_one_gpu():
     assert total_steps < 1.05 * 2 * 256 * 120   # a game makes at most one step per iteration
     assert out["games_finished_in_timed_region"] == out["games_per_s"] * out["ms_per_step"] * 2e-3 or out["games_per_s"] > 0
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["launches_timed"] > 0
+
+
+def test_bench_py_rank_over_rccl():
+    """What every rank of an N > 1 run does, rehearsed with one rank (AZH_DIST_FORCE=1): torch's HIP runtime and the
+    RCCL communicator come up first (init_process_group("nccl") + a device barrier), this package's library second,
+    in the same process; the barriers and the reductions around the timed region go through RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "AZH_DIST_BACKEND")}
+    env.update(AZH_DIST_FORCE="1", MASTER_PORT="29533")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--iters-per-step", "60", "--games", "256", "--visits", "16", "--blocks", "2",
+                          "--phase-fill", "30", "--no-cpu-baseline", "--no-target-leg"], env=env, cwd=ROOT,
+                         capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    out = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["counters"]["steps"] > 0
+    assert out["config"]["timing_barrier_backend"] == "nccl"
+    assert 0 < out["roofline"]["frac"] < 1
