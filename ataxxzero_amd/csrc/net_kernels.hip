@@ -975,7 +975,11 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
         conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 0, 1, true, wrsrc, A.conv_w2, wp, aring, sh, t1 + 2 * F, vmask, cellv, wave, lane,
                                                 st + 12 + 8 * b);
         __syncthreads();
-        if constexpr (STAMP) st[12 + 8 * b + 3] = stamp_now();
+        if constexpr (STAMP) {
+            st[12 + 8 * b + 3] = stamp_now();
+            if (b < 16)
+                st[105 + b] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one base for the chip: the shader clock block by block
+        }
         wp += lf;
     }
 }
@@ -1004,6 +1008,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     if constexpr (STAMP) {
         st = A.stamps + ((size_t)blockIdx.x * OCT + wave) * 128;
         st[0] = stamp_now();
+        st[3] = __builtin_amdgcn_s_memrealtime();
     }
     for (int i = tid * 16; i < G::LDS_BYTES; i += NTHREADS * 16)
         *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
@@ -1074,7 +1079,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
             s = __builtin_fmaf(*reinterpret_cast<const float *>(smem + G::vcell_off(21 * (c % 7) + 7 * tid + c / 7)), A.fc_w[c], s);
         A.values[game] = tanhf(s + A.fc_b);
     }
-    if constexpr (STAMP) st[2] = stamp_now();
+    if constexpr (STAMP) {
+        st[2] = stamp_now();
+        st[104] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ------------------------------------------------------------------ host side

@@ -46,3 +46,31 @@ for n in [int(a) for a in sys.argv[1:]] or [1536, 3600]:
     ts = np.linspace(0, te.max(), 41)
     occ = [(int(((t0 <= t) & (te > t)).sum())) for t in ts]
     print("  resident workgroups at 40 equal time steps: %s" % occ)
+
+# ---- second pass with the constant-rate clock (s_memrealtime, 100 MHz, one base for the whole chip)
+print()
+print("real-time view (s_memrealtime, 10 ns units): when workgroups run and what the shader clock is while they do")
+for n in [int(a) for a in sys.argv[1:]] or [1536, 3600]:
+    wgs = (n + 2) // 3
+    st = net.stamps(n, wgs=wgs).astype(np.int64)
+    r0 = st[:, 0, 3]
+    r1 = st[:, 0, 104]
+    base = r0.min()
+    span_us = (r1.max() - base) / 100.0
+    starts = (r0 - base) / 100.0
+    ends = (r1 - base) / 100.0
+    print("n=%d: span %.0f us; starts p50 %.0f p90 %.0f max %.0f us; workgroup life p10 %.0f p50 %.0f p90 %.0f us" % (
+        (n, span_us) + tuple(np.percentile(starts, [50, 90, 100])) + tuple(np.percentile(ends - starts, [10, 50, 90]))))
+    ts = np.linspace(0, span_us, 21)
+    print("  resident workgroups every %.0f us: %s" % (ts[1], [int(((starts <= t) & (ends > t)).sum()) for t in ts]))
+    # clock: shader cycles between the ends of consecutive residual blocks over the real time between them
+    cyc = np.stack([st[:, 0, 12 + 8 * b + 3] for b in range(BLOCKS)], axis=1)
+    rt = np.stack([st[:, 0, 105 + b] for b in range(BLOCKS)], axis=1)
+    ghz = np.diff(cyc, axis=1) / (np.diff(rt, axis=1) * 10.0)       # cycles per ns
+    mid = ((rt[:, 1:] + rt[:, :-1]) / 2 - base) / 100.0
+    bins = np.linspace(0, span_us, 13)
+    out = []
+    for a, b in zip(bins[:-1], bins[1:]):
+        m = (mid >= a) & (mid < b)
+        out.append("%.2f" % ghz[m].mean() if m.any() else "-")
+    print("  shader clock (GHz) in 12 equal slices of the span: %s" % " ".join(out))
