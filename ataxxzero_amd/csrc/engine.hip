@@ -1546,9 +1546,9 @@ extern "C" int azh_engine_set_positions(azh_engine *e, const uint64_t *boards, c
     }
     ulonglong2 *d_b = nullptr;
     int *d_p = nullptr;
-    AZH_HIP(hipMalloc((void **)&d_b, G * 16));
-    AZH_HIP(hipMalloc((void **)&d_p, G * 4));
-    hipError_t rc = hipMemcpy(d_b, boards, G * 16, hipMemcpyHostToDevice);
+    hipError_t rc = hipMalloc((void **)&d_b, G * 16);
+    if (rc == hipSuccess) rc = hipMalloc((void **)&d_p, G * 4);
+    if (rc == hipSuccess) rc = hipMemcpy(d_b, boards, G * 16, hipMemcpyHostToDevice);
     if (rc == hipSuccess) rc = hipMemcpy(d_p, plies, G * 4, hipMemcpyHostToDevice);
     if (rc == hipSuccess) rc = hipMemsetAsync(e->P.adv_count, 0, sizeof(int), e->stream);
     if (rc == hipSuccess) {
