@@ -596,6 +596,9 @@ constexpr int RING2 = AZH_RING2;
 #ifndef AZH_UNIFORM_WAVE
 #define AZH_UNIFORM_WAVE 1
 #endif
+#ifndef AZH_ROWS_LATE
+#define AZH_ROWS_LATE 1
+#endif
 #ifndef AZH_FIRSTC
 #define AZH_FIRSTC 1   /* +0.9 % at 16 K boards, +1.0 % at 3.6 K (profiles/round2_tower_variants.txt, call 5) */
 #endif
@@ -802,7 +805,8 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             constexpr int rs = (ring0 + j) % RING2;
             constexpr int j1 = j + 1;
             constexpr int i1 = (j1 / KS) % 3, ks1 = j1 % KS;
-            if constexpr (ks == 0) {  // offsets of the tap after this one (it may belong to the next row)
+            constexpr bool rows_late = AZH_ROWS_LATE && KS > 1;  // (with one k-step per tap the offsets are needed at once)
+            if constexpr (ks == 0 && !rows_late) {  // offsets of the tap after this one (it may belong to the next row)
                 const int o1 = i == 2 ? (o < 2 ? o + 1 : 2) : o;
                 rows_for(o1, IC<(i + 1) % 3>(), nxt);
             }
@@ -812,6 +816,12 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             else
                 load_b(b[par ^ 1], cur, ks1, IC<i1>());
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ks == 0 && rows_late) {
+                // the next tap's offsets are first used KS - 1 steps from here: their address arithmetic goes behind the
+                // barrier, where it can issue between this step's MFMAs instead of ahead of them
+                const int o1 = i == 2 ? (o < 2 ? o + 1 : 2) : o;
+                rows_for(o1, IC<(i + 1) % 3>(), nxt);
+            }
 #if AZH_SETPRIO
             __builtin_amdgcn_s_setprio(AZH_SETPRIO);  // tuning experiment (tools/tower_variants.sh): MFMA cluster at raised priority
 #endif
