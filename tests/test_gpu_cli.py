@@ -354,7 +354,11 @@ def test_bench_py_rank_over_rccl():
     RCCL communicator come up first (init_process_group("nccl") + a device barrier), this package's library second,
     in the same process; the barriers and the reductions around the timed region go through RCCL."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "AZH_DIST_BACKEND")}
-    env.update(AZH_DIST_FORCE="1", MASTER_PORT="29533")
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env.update(AZH_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                           "--iters-per-step", "60", "--games", "256", "--visits", "16", "--blocks", "2",
                           "--phase-fill", "30", "--no-cpu-baseline", "--no-target-leg"], env=env, cwd=ROOT,
