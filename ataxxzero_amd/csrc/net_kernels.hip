@@ -599,6 +599,9 @@ constexpr int RING2 = AZH_RING2;
 #ifndef AZH_ROWS_LATE
 #define AZH_ROWS_LATE 1
 #endif
+#ifndef AZH_OOBZERO
+#define AZH_OOBZERO 1   /* +1.5 % at 16 K boards, +1.3 % at 3.6 K (profiles/round2_tower_variants.txt, call 9) */
+#endif
 #ifndef AZH_FIRSTC
 #define AZH_FIRSTC 1   /* +0.9 % at 16 K boards, +1.0 % at 3.6 K (profiles/round2_tower_variants.txt, call 5) */
 #endif
@@ -711,11 +714,20 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         typename Tr::quad sk[4][TPW];
 #pragma unroll
         for (int ct = 0; ct < TPW; ct++) {
+#if AZH_OOBZERO
+            // cellv = kg * CS + cell * UB, the empty-lane flag is bit 9 of vmask: an empty lane reads past the end of LDS
+            const int base = (cellv[ct] - kg * G::CS + out_img * ((G::NC + G::Z) * G::UB)) +
+                             (int)(__builtin_amdgcn_ubfe((unsigned)vmask[ct], 9, 1) << 28);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                sk[t][ct] = *reinterpret_cast<const typename Tr::quad *>(lds + base + G::ch_off(0, 64 * oh + 16 * t + 4 * kg));
+#else
             const int cell = cellv[ct] & 0xFF;
             const int slot = (cellv[ct] & 0x100) ? G::zero_slot(out_img, cell) : G::real_slot(out_img, cell);
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 sk[t][ct] = *reinterpret_cast<const typename Tr::quad *>(lds + G::ch_off(slot, 64 * oh + 16 * t + 4 * kg));
+#endif
         }
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -777,9 +789,19 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         static_for<0, TPW>([&](auto ct_tag) {
             constexpr int ct = decltype(ct_tag)::value;
             if constexpr (!skip_pair(ct, i)) {
+#if AZH_OOBZERO
+                // An LDS read past the workgroup's allocation returns zeros (tools/microbench/lds_oob.hip): a tap that
+                // looks off the board sets bit 28 of its byte address instead of being steered to a zero slot — three
+                // instructions per (tile, tap): neighbour offset, the tap's bit of the lane's off-board mask, merge.
+                const unsigned c16 = (unsigned)(cellv[ct] + (drow + in_img * (G::NC + G::Z)) * G::UB);
+                // (added, not or-ed: for an off-board tap c16 may be a small negative number, and 2^28 + c16 stays far out
+                // of range with the k-step's immediate offset on top, where 0xFFFFFxxx would wrap back into the image)
+                dst[ct] = (int)((__builtin_amdgcn_ubfe((unsigned)vmask[ct], (unsigned)tap, 1) << 28) + c16);
+#else
                 const int c = (cellv[ct] & 0xFF) + drow;
                 const int slot = ((vmask[ct] >> tap) & 1) ? G::real_slot(in_img, c) : G::zero_slot(in_img, c);
                 dst[ct] = kg * G::CS + slot * G::UB;
+#endif
             }
         });
     };
@@ -886,8 +908,13 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     // epilogue: relu, convert, write 4 channels (8 bytes) per (A tile, cell tile)
 #pragma unroll
     for (int ct = 0; ct < TPW; ct++) {
+#if AZH_OOBZERO
+        if (!(vmask[ct] & 0x200)) {
+            const int cellq = cellv[ct] - kg * G::CS + out_img * ((G::NC + G::Z) * G::UB);  // byte offset of the cell's slot
+#else
         if (!(cellv[ct] & 0x100)) {
             const int cell = cellv[ct];
+#endif
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 float v[4];
@@ -914,7 +941,11 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
                 packed.x = __builtin_bit_cast(unsigned, plo);
                 packed.y = __builtin_bit_cast(unsigned, phi);
 #endif
+#if AZH_OOBZERO
+                *reinterpret_cast<uint2 *>(lds + cellq + G::ch_off(0, 64 * oh + 16 * t + 4 * kg)) = packed;
+#else
                 *reinterpret_cast<uint2 *>(lds + G::ch_off(G::real_slot(out_img, cell), 64 * oh + 16 * t + 4 * kg)) = packed;
+#endif
             }
         }
     }
@@ -946,6 +977,12 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
                 }
             }
             vmask[ct] = m;
+#if AZH_OOBZERO
+            // bit set = the tap looks off the board; bit 9 = empty lane (all taps off); cellv = byte offset of the lane's
+            // cell in a unit plus the lane's k-group row
+            vmask[ct] = (cv & 0x100) ? 0x3FF : (~m & 0x1FF);
+            cellv[ct] = (lane >> 4) * G::CS + (cv & 0xFF) * G::UB;
+#endif
         }
     }
     const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w2);
