@@ -1275,6 +1275,68 @@ static int net_pack(azh_net *net, int dt)
     return 0;
 }
 
+constexpr int MAX_DEVICES = 64;
+static int current_device()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
+        return -1;
+    return dev;
+}
+
+#if AZH_OOBZERO
+// Variant 2 relies on the LDS range check: a ds_read beyond the workgroup's allocation must return zeros.  Checked once
+// per device and process before the first net is handed out (reads at 80 KiB, 160 KiB and 2^28 past a 4 KiB allocation
+// filled with ones, with and without an instruction offset): a device that answered anything else would make every
+// board edge wrong, so the library refuses to run there (rebuild with -DAZH_OOBZERO=0).
+__global__ void k_lds_range_probe(unsigned *out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+        reinterpret_cast<unsigned *>(smem)[i] = 0x01010101u;
+    __syncthreads();
+    const unsigned addrs[3] = {81920u + 16u * threadIdx.x, 163840u + 16u * threadIdx.x, (1u << 28) + 16u * threadIdx.x - 352u};
+    unsigned any = 0;
+    for (int k = 0; k < 3; k++) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v, w;
+        asm volatile("ds_read_b128 %0, %1 offset:61440\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addrs[k]) : "memory");
+        asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(addrs[k]) : "memory");
+        any |= v.x | v.y | v.z | v.w | w.x | w.y | w.z | w.w;
+    }
+    const unsigned inside = reinterpret_cast<const unsigned *>(smem)[threadIdx.x];
+    if (any)
+        atomicOr(out, 1u);
+    if (inside != 0x01010101u)
+        atomicOr(out, 2u);
+}
+
+static int lds_range_check_ok()
+{
+    static int state[MAX_DEVICES] = {};  // 0 unknown, 1 ok, -1 failed
+    const int dev = current_device();
+    if (dev < 0)
+        return azh_fail(-4, "lds_range_check: hipGetDevice failed");
+    if (state[dev] == 0) {
+        unsigned *d = nullptr, h = 0xFFu;
+        AZH_HIP(hipMalloc((void **)&d, 4));
+        hipError_t rc = hipMemset(d, 0, 4);
+        if (rc == hipSuccess) {
+            hipLaunchKernelGGL(k_lds_range_probe, dim3(1), dim3(64), 4096, 0, d);
+            rc = hipGetLastError();
+        }
+        if (rc == hipSuccess) rc = hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        AZH_HIP(rc);
+        state[dev] = h == 0 ? 1 : -1;
+    }
+    if (state[dev] < 0)
+        return azh_fail(-5, "this device does not return zeros for LDS reads beyond the workgroup's allocation; "
+                            "rebuild the library with -DAZH_OOBZERO=0");
+    return 0;
+}
+#endif
+
 extern "C" int azh_net_create(int blocks, int filters, const float *conv_flat, const float *bn_flat,
                               float bn_eps, azh_net **out)
 {
@@ -1287,6 +1349,10 @@ extern "C" int azh_net_create(int blocks, int filters, const float *conv_flat, c
         return azh_fail(-2, "azh_net_create: bad block count %d", blocks);
     if (azh_require_device())
         return -3;
+#if AZH_OOBZERO
+    if (int rc = lds_range_check_ok())
+        return rc;
+#endif
     azh_net *net = new azh_net();
     net->blocks = blocks;
     net->filters = filters;
@@ -1304,10 +1370,14 @@ extern "C" int azh_net_create(int blocks, int filters, const float *conv_flat, c
     const float *fc = conv_flat + n_conv - 50;
     net->fc_b = fc[49];
     net->scale = scale;
-    AZH_HIP(hipMalloc((void **)&net->d_shift, shift.size() * 4));
-    AZH_HIP(hipMalloc((void **)&net->d_fcw, 49 * 4));
-    AZH_HIP(hipMemcpy(net->d_shift, shift.data(), shift.size() * 4, hipMemcpyHostToDevice));
-    AZH_HIP(hipMemcpy(net->d_fcw, fc, 49 * 4, hipMemcpyHostToDevice));
+    hipError_t rc = hipMalloc((void **)&net->d_shift, shift.size() * 4);
+    if (rc == hipSuccess) rc = hipMalloc((void **)&net->d_fcw, 49 * 4);
+    if (rc == hipSuccess) rc = hipMemcpy(net->d_shift, shift.data(), shift.size() * 4, hipMemcpyHostToDevice);
+    if (rc == hipSuccess) rc = hipMemcpy(net->d_fcw, fc, 49 * 4, hipMemcpyHostToDevice);
+    if (rc != hipSuccess) {
+        azh_net_destroy(net);  // frees whatever was allocated
+        AZH_HIP(rc);
+    }
     *out = net;
     return 0;
 }
@@ -1327,14 +1397,6 @@ extern "C" void azh_net_destroy(azh_net *net)
     delete net;
 }
 
-constexpr int MAX_DEVICES = 64;
-static int current_device()
-{
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
-        return -1;
-    return dev;
-}
 
 template <int DT, int NB, int WPS, bool STAMP = false, int FT = F>
 static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
