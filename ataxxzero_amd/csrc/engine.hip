@@ -253,9 +253,8 @@ __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
 
 // ------------------------------------------------------------------ select + expand
 
-__device__ inline void select_game(const EngineParams &P, int g, TreeLds &L)
+__device__ inline void select_game(const EngineParams &P, int g, u16 *s_moves)
 {
-    u16 *s_moves = L.moves;
     const int lane = lane_id();
     azh_game_state s = P.gs[g];
     Arena A = arena_of(P, s.arena, g);
@@ -1044,8 +1043,8 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
 // backup -> mark -> select, so a step costs one launch instead of three.
 __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
 {
-    __shared__ TreeLds L;
-    select_game(P, blockIdx.x, L);
+    __shared__ u16 s_moves[MAX_MOVES];  // the move list of the node being expanded: all the scratch a descent needs
+    select_game(P, blockIdx.x, s_moves);
 }
 
 __global__ __launch_bounds__(WAVE) void k_backup(EngineParams P) { backup_game(P, blockIdx.x); }
@@ -1077,16 +1076,18 @@ __global__ __launch_bounds__(WAVE) void k_advance_list(EngineParams P)
     }
 }
 
+// (512 B of LDS per game wave, not the re-root's 7 KiB: at 16384 games the resident game waves are then bounded by
+// registers alone)
 __global__ __launch_bounds__(WAVE) void k_tree(EngineParams P, int with_select)
 {
-    __shared__ TreeLds L;
+    __shared__ u16 s_moves[MAX_MOVES];
     const int g = blockIdx.x;
     backup_game(P, g);
     __syncthreads();
     mark_game(P, g);
     __syncthreads();
     if (with_select)
-        select_game(P, g, L);
+        select_game(P, g, s_moves);
 }
 
 // Reference feature rows for the dense leaf list (cpp/self_play_client.cpp:174-202).
