@@ -130,6 +130,17 @@ __host__ __device__ inline int policy_index(u32 move)
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 
+// One wave owns a game; several such waves share a workgroup and take different paths, so nothing inside a game's
+// code may wait for the other waves.  What the game's 64 lanes hand each other through LDS or global memory needs only
+// this: earlier accesses of the wave are complete (workgroup-scope fence = the waitcnt a __syncthreads() would issue) and
+// the compiler keeps later ones behind it.  LDS and the CU's vector L1 serve a wave's accesses in issue order.
+__device__ inline void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Cross-lane traffic goes through DPP (VALU speed), not ds_bpermute (an LDS round trip per
 // hop): the PUCT descent is a dependent chain of ~15 reductions per tree level.
 // gfx9 DPP controls: quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_mirror 0x140,

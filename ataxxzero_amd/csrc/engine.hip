@@ -41,6 +41,8 @@ constexpr int REC_STRIDE_WORDS = REC_HDR_WORDS + REC_MAXD;
 constexpr u32 RING_MAGIC = 0x415A4847u;  // "AZHG"
 constexpr int NSTAT = AZH_STAT_COUNT;
 constexpr int BFS_QL = 384;  // re-root frontier entries kept in LDS; later ones spill to bfs_spill in HBM
+constexpr int TREE_WAVES = 4;  // games (one wave each) per workgroup of the fused tree kernel
+constexpr int TREE_THREADS = TREE_WAVES * WAVE;
 
 struct EngineParams {
     int G, visits, node_cap, edge_cap, path_cap, max_plies;
@@ -71,6 +73,7 @@ struct EngineParams {
     int *leaf_count;
     int *leaf_list2;   // arena: leaves of the games whose mover is net B
     int *leaf_count2;
+    int *tree_done;    // tickets of the workgroups of a k_tree launch (the last one compacts the leaf list)
     float *logits;
     float *values;
     u32 *rec;
@@ -190,7 +193,7 @@ __device__ inline void init_game_at(const EngineParams &P, int g, u32 uid, azh_g
     Arena A = arena_of(P, 0, g);
     int res;
     const int M = wave_movegen(b, P.blockers, s_moves, &res);
-    __syncthreads();
+    wave_sync();
     for (int j = lane; j < M; j += WAVE) {
         A.ed[j] = make_uint4(0u, 0u, 0u, NONE);
         A.em[j] = s_moves[j];
@@ -204,7 +207,7 @@ __device__ inline void init_game_at(const EngineParams &P, int g, u32 uid, azh_g
     }
     if (P.flags & AZH_FLAG_EVAL_CACHE)
         tt_clear(tt_of(P, 0, g), P.tt_size);
-    __syncthreads();
+    wave_sync();
     s.phase = 0;
     s.arena = 0;
     s.n_nodes = 1;
@@ -253,15 +256,15 @@ __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
 
 // ------------------------------------------------------------------ select + expand
 
-__device__ inline void select_game(const EngineParams &P, int g, u16 *s_moves)
+// `s` is the game's state, held in registers by the caller (the same values in all 64 lanes); written back here.
+__device__ inline void select_game(const EngineParams &P, int g, azh_game_state &s, u16 *s_moves)
 {
     const int lane = lane_id();
-    azh_game_state s = P.gs[g];
     Arena A = arena_of(P, s.arena, g);
     int *path = P.path + (size_t)g * P.path_cap;
 
     int kind = AZH_LEAF_NONE, leaf_node = 0, depth = 0, over = 0;
-    u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0, st_cached = 0;
+    u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0, st_cached = 0, st_parked = 0;
     u64 leaf_mover = 0, leaf_opp = 0;
 
     if (s.phase == 2) {
@@ -294,6 +297,7 @@ __device__ inline void select_game(const EngineParams &P, int g, u16 *s_moves)
             if (P.select_budget != 0 && levels_done == P.select_budget) {
                 kind = AZH_LEAF_DESCENT;  // park: no leaf for the evaluator from this game this iteration
                 leaf_node = (int)node;
+                st_parked = 1;
                 break;
             }
             levels_done++;
@@ -416,7 +420,7 @@ __device__ inline void select_game(const EngineParams &P, int g, u16 *s_moves)
             const Board cb = make_move(unpack_board(pw.x, pw.y), (int)(mv & 0xFF), (int)(mv >> 8));
             int res2;
             const int M2 = wave_movegen(cb, P.blockers, s_moves, &res2);
-            __syncthreads();
+            wave_sync();
             if (s.n_nodes >= P.node_cap || (res2 == 0 && s.n_edges + M2 > P.edge_cap)) {
                 over = 1;
                 kind = AZH_LEAF_NONE;
@@ -477,15 +481,16 @@ __device__ inline void select_game(const EngineParams &P, int g, u16 *s_moves)
         }
     }
 
+    s.leaf_kind = kind;
+    s.leaf_node = leaf_node;
+    s.path_len = depth;
     if (lane == 0) {
-        s.leaf_kind = kind;
-        s.leaf_node = leaf_node;
-        s.path_len = depth;
         P.gs[g] = s;
         int need = (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) ? 1 : 0;
         if (need && (P.flags & AZH_FLAG_TWO_NETS))
             need = 1 + ((s.ply + g) & 1);  // net A (1) / net B (2) is to move; even slots give x to A
-        P.need_eval[g] = need;
+        // write-through (agent scope): the workgroup that finishes last reads every game's flag (compact_leaves)
+        __hip_atomic_store(&P.need_eval[g], need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         P.leaf_board[g] = make_ulonglong2(leaf_mover, leaf_opp);
         if (over)
             P.force[g] = 1;
@@ -497,7 +502,8 @@ __device__ inline void select_game(const EngineParams &P, int g, u16 *s_moves)
                       : lane == AZH_STAT_CHILDREN ? st_children
                       : lane == AZH_STAT_NEW_MOVES ? st_newmoves
                       : lane == AZH_STAT_EDGE_OVERFLOW ? (u64)(over == 1)
-                      : lane == AZH_STAT_CACHE_HITS ? st_cached : 0ull;
+                      : lane == AZH_STAT_CACHE_HITS ? st_cached
+                      : lane == AZH_STAT_PARKED ? st_parked : 0ull;
         if (lane < NSTAT)
             add_stat(P, g, lane, inc);
     }
@@ -531,10 +537,10 @@ __global__ __launch_bounds__(1024) void k_compact(const int *need, int G, int *l
 
 // ------------------------------------------------------------------ priors + backup
 
-__device__ inline void backup_game(const EngineParams &P, int g)
+// `s`: the game's state in the caller's registers (uniform over the lanes); updated, not stored.
+__device__ inline void backup_game(const EngineParams &P, int g, azh_game_state &s)
 {
     const int lane = lane_id();
-    azh_game_state s = P.gs[g];
     const int kind = s.leaf_kind;
     if (kind == AZH_LEAF_NONE || kind == AZH_LEAF_DESCENT)
         return;  // nothing evaluated; a parked descent keeps its state
@@ -668,12 +674,9 @@ __device__ inline void backup_game(const EngineParams &P, int g)
         if (s.path_len > 0)
             s.root_visits += 1;
     }
-    if (lane == 0) {
-        if (kind == AZH_LEAF_ROOT)
-            s.phase = 1;
-        s.leaf_kind = AZH_LEAF_NONE;
-        P.gs[g] = s;
-    }
+    if (kind == AZH_LEAF_ROOT)
+        s.phase = 1;
+    s.leaf_kind = AZH_LEAF_NONE;
 }
 
 // ------------------------------------------------------------------ ply advance
@@ -738,7 +741,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
                 s_w[j] = (2 * n >= maxn) ? n * n * n * n * n : 0ull;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (lane == 0) {
             u64 T = 0;
             for (int j = 0; j < M; j++)
@@ -754,9 +757,9 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
             }
             s_pref[0] = (u32)c;
         }
-        __syncthreads();
+        wave_sync();
         chosen = (int)s_pref[0];
-        __syncthreads();
+        wave_sync();
     } else {
         u32 run = 0;
 #pragma unroll
@@ -827,12 +830,12 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     // MCTS::play (:475-492): keep the chosen child's subtree, compacted breadth-first
     // into the other arena (children keep their edge order).
     int result;
-    u64 st_nodes = 0, st_edges = 0;
+    u64 st_nodes = 0, st_edges = 0, st_spill = 0;
     if (c == NONE) {
         // miss: fresh tree from the position after the move (:479-483)
         const Board nbrd = make_move(unpack_board(rootw.x, rootw.y), (int)(mv & 0xFF), (int)(mv >> 8));
         const int Mn = wave_movegen(nbrd, P.blockers, s_moves, &result);
-        __syncthreads();
+        wave_sync();
         const int Mw = result != 0 ? 0 : Mn;
         for (int j = lane; j < Mw; j += WAVE) {
             B.ed[j] = make_uint4(0u, 0u, 0u, NONE);
@@ -861,7 +864,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
         u32 t = 1, eb = 0, rv = 0, qs = 0;
         if (lane == 0)
             q_put(0u, c, cinfo.x, cinfo.y, 0u);
-        __syncthreads();
+        wave_sync();
         while (qs < t) {
             const u32 nchunk = min(t - qs, (u32)WAVE);
             u32 of = 0, Mq = 0, qy = 0, old = 0, pe = 0;
@@ -886,7 +889,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
             }
             if (lane == 0)
                 s_pref[nchunk] = Ef;
-            __syncthreads();
+            wave_sync();
             for (u32 e0 = 0; e0 < Ef; e0 += WAVE) {
                 const u32 e = e0 + (u32)lane;
                 const bool valid = e < Ef;
@@ -925,13 +928,14 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
             }
             eb += Ef;
             qs += nchunk;
-            __syncthreads();
+            wave_sync();
         }
         s.n_nodes = (int)t;
         s.n_edges = (int)eb;
         s.root_visits = (int)wave_sum_u32(rv);
         st_nodes = t;
         st_edges = eb;
+        st_spill = t > (u32)BFS_QL ? 1 : 0;
     }
     if (P.flags & AZH_FLAG_EVAL_CACHE) {
         // the kept subtree's evaluations stay usable: rebuild the table of the new arena from its nodes (all but the
@@ -939,7 +943,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
         u32 *tt = tt_of(P, 1 - s.arena, g);
         tt_clear(tt, P.tt_size);
         __threadfence();
-        __syncthreads();
+        wave_sync();
         for (u32 n = 1u + (u32)lane; n < (u32)s.n_nodes; n += WAVE) {
             const uint4 info = B.ni[n];
             if ((info.y >> 16) == 0u && (info.y & 0xFFFFu) != 0u) {
@@ -950,7 +954,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     }
     s.arena = 1 - s.arena;
     s.ply += 1;
-    __syncthreads();
+    wave_sync();
 
     u64 st_games = 0, st_dropped = 0, st_ring = 0;
     const bool cut = result == 0 && s.ply >= P.max_plies;
@@ -1033,7 +1037,8 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
                       : lane == AZH_STAT_DROPPED ? (u64)st_dropped
                       : lane == AZH_STAT_RING_OVERFLOW ? (u64)st_ring
                       : lane == AZH_STAT_REROOT_NODES ? st_nodes
-                      : lane == AZH_STAT_REROOT_EDGES ? st_edges : 0ull;
+                      : lane == AZH_STAT_REROOT_EDGES ? st_edges
+                      : lane == AZH_STAT_REROOT_SPILLS ? st_spill : 0ull;
         if (lane < NSTAT)
             add_stat(P, g, lane, inc);
     }
@@ -1044,27 +1049,43 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
 __global__ __launch_bounds__(WAVE) void k_select(EngineParams P)
 {
     __shared__ u16 s_moves[MAX_MOVES];  // the move list of the node being expanded: all the scratch a descent needs
-    select_game(P, blockIdx.x, s_moves);
+    azh_game_state s = P.gs[blockIdx.x];
+    select_game(P, blockIdx.x, s, s_moves);
 }
 
-__global__ __launch_bounds__(WAVE) void k_backup(EngineParams P) { backup_game(P, blockIdx.x); }
+__global__ __launch_bounds__(WAVE) void k_backup(EngineParams P)
+{
+    const int g = blockIdx.x;
+    azh_game_state s = P.gs[g];
+    const int kind = s.leaf_kind;
+    backup_game(P, g, s);
+    if (kind != AZH_LEAF_NONE && kind != AZH_LEAF_DESCENT && threadIdx.x == 0)
+        P.gs[g] = s;
+}
 
 // while (root.all_edge_visits < global_visits) step();  (:522-525): once the threshold is reached the move is due.
 // The game is only MARKED here (phase 2) and queued; the next select gives it no leaf, and the re-root
 // (advance_game) then runs from the queue in its own launch, beside the tower of the other games — a deep
 // subtree copy (one dependent round trip per tree level) no longer sits on every iteration's critical path.
-__device__ inline void mark_game(const EngineParams &P, int g)
+// `forced`: force[g], loaded by the caller beside the state.
+__device__ inline void mark_game(const EngineParams &P, int g, azh_game_state &s, int forced)
 {
-    if (lane_id() != 0)
-        return;
-    const azh_game_state s = P.gs[g];
-    if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= P.visits || P.force[g] != 0)) {
-        P.gs[g].phase = 2;
-        P.adv_list[atomicAdd(P.adv_count, 1)] = g;
+    if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= P.visits || forced != 0)) {
+        s.phase = 2;
+        if (lane_id() == 0)
+            P.adv_list[atomicAdd(P.adv_count, 1)] = g;
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_mark(EngineParams P) { mark_game(P, blockIdx.x); }
+__global__ __launch_bounds__(WAVE) void k_mark(EngineParams P)
+{
+    const int g = blockIdx.x;
+    azh_game_state s = P.gs[g];
+    const int phase = s.phase;
+    mark_game(P, g, s, P.force[g]);
+    if (s.phase != phase && threadIdx.x == 0)
+        P.gs[g] = s;
+}
 
 __global__ __launch_bounds__(WAVE) void k_advance_list(EngineParams P)
 {
@@ -1072,22 +1093,86 @@ __global__ __launch_bounds__(WAVE) void k_advance_list(EngineParams P)
     const int n = *P.adv_count;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         advance_game(P, P.adv_list[i], L);
-        __syncthreads();
+        wave_sync();
     }
 }
 
-// (512 B of LDS per game wave, not the re-root's 7 KiB: at 16384 games the resident game waves are then bounded by
-// registers alone)
-__global__ __launch_bounds__(WAVE) void k_tree(EngineParams P, int with_select)
+// The dense, game-ordered leaf list(s) of k_compact, written inside the tree launch by the workgroup that finishes
+// last (each workgroup draws a ticket from an agent-scope counter once its games have stored their flags; the flags
+// are stored and loaded write-through / L1-bypassing, so no fence is needed: MI355X_MICROARCH.md, hand-off forms).
+// One kernel and one kernel boundary less per search iteration.
+__device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt /* [2][TREE_WAVES] */)
 {
-    __shared__ u16 s_moves[MAX_MOVES];
-    const int g = blockIdx.x;
-    backup_game(P, g);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int c = (P.G + TREE_THREADS - 1) / TREE_THREADS;  // consecutive games per thread
+    const int lo = min(P.G, t * c), hi = min(P.G, lo + c);
+    int n1 = 0, n2 = 0;
+    for (int i = lo; i < hi; i++) {
+        const int v = __hip_atomic_load(&P.need_eval[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n1 += two ? v == 1 : v != 0;
+        n2 += two && v == 2;
+    }
+    const int i1 = wave_incl_scan(n1), i2 = wave_incl_scan(n2);
+    if (lane == WAVE - 1) {
+        s_cnt[w] = i1;
+        s_cnt[TREE_WAVES + w] = i2;
+    }
     __syncthreads();
-    mark_game(P, g);
+    int b1 = i1 - n1, b2 = i2 - n2, t1 = 0, t2 = 0;
+#pragma unroll
+    for (int k = 0; k < TREE_WAVES; k++) {
+        b1 += k < w ? s_cnt[k] : 0;
+        b2 += k < w ? s_cnt[TREE_WAVES + k] : 0;
+        t1 += s_cnt[k];
+        t2 += s_cnt[TREE_WAVES + k];
+    }
+    for (int i = lo; i < hi; i++) {
+        const int v = __hip_atomic_load(&P.need_eval[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (two ? v == 1 : v != 0)
+            P.leaf_list[b1++] = i;
+        if (two && v == 2)
+            P.leaf_list2[b2++] = i;
+    }
+    if (t == 0) {
+        *P.leaf_count = t1;
+        if (two)
+            *P.leaf_count2 = t2;
+        __hip_atomic_store(P.tree_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The tree phase of a search iteration as ONE launch: a wave owns a game through backup -> "is the move due?" ->
+// the next select, with the game's state in registers throughout; TREE_WAVES games share a workgroup (each wave on
+// its own: wave_sync, never a workgroup barrier, inside a game), and the last workgroup to finish compacts the leaf
+// list.  mode bit 0: backup + mark, bit 1: select (+ compaction).
+__global__ __launch_bounds__(TREE_THREADS) void k_tree(EngineParams P, int mode, int two)
+{
+    __shared__ u16 s_moves[TREE_WAVES][MAX_MOVES];  // per game: the move list of the node being expanded
+    __shared__ int s_cnt[2 * TREE_WAVES];
+    __shared__ int s_last;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the game's addresses are scalars
+    const int g = blockIdx.x * TREE_WAVES + w;
+    if (g < P.G) {
+        azh_game_state s = P.gs[g];
+        const int forced = P.force[g];  // (same round trip as the state)
+        if (mode & 1) {
+            backup_game(P, g, s);
+            mark_game(P, g, s, forced);
+        }
+        if (mode & 2)
+            select_game(P, g, s, s_moves[w]);  // stores the state
+        else if (lane_id() == 0)
+            P.gs[g] = s;
+    }
+    if (!(mode & 2))
+        return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's flag has left the CU
     __syncthreads();
-    if (with_select)
-        select_game(P, g, s_moves);
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(P.tree_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (s_last)
+        compact_leaves(P, two, s_cnt);
 }
 
 // Reference feature rows for the dense leaf list (cpp/self_play_client.cpp:174-202).
@@ -1151,6 +1236,7 @@ struct azh_engine {
     bool emit_by_uid = false;
     std::map<uint32_t, std::string> held;
     uint32_t next_uid = 0;
+    bool order_broken = false;  // records were lost (ring overflow): some uid will never come, see azh_engine_drain_json
     // timing: every `timing_stride`-th iteration of the device loop is bracketed by events on the engine's stream
     // (tower start, tower end, start of the next tower = end of the tree phase).  Sampling keeps the event packets —
     // each a barrier in the queue, a few microseconds — out of most iterations of the region being measured.
@@ -1235,6 +1321,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.leaf_count, 1);
     rc |= dev_alloc(e, &P.leaf_list2, G);
     rc |= dev_alloc(e, &P.leaf_count2, 1);
+    rc |= dev_alloc(e, &P.tree_done, 1);
     rc |= dev_alloc(e, &P.logits, G * AZH_POLICY_SIZE);
     rc |= dev_alloc(e, &P.values, G);
     rc |= dev_alloc(e, &P.rec, G * P.max_plies * REC_STRIDE_WORDS);
@@ -1247,7 +1334,12 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
         azh_engine_destroy(e);
         return rc;
     }
-    if (hipStreamCreate(&e->stream) != hipSuccess || hipStreamCreate(&e->stream2) != hipSuccess ||
+    // the side stream of the re-roots gets the highest priority the device offers: its few waves must not queue
+    // behind the tower's 1,200 workgroups for the slots those free
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (hipStreamCreate(&e->stream) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream2, hipStreamDefault, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_sel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_adv, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&e->h_count, sizeof(int)) != hipSuccess) {
@@ -1297,7 +1389,7 @@ extern "C" int azh_engine_edge_cap(const azh_engine *e) { return e ? e->P.edge_c
 
 static int enqueue_compact(azh_engine *e);
 
-constexpr int ADV_GRID = 256;
+constexpr int ADV_GRID = 64;  // one wave each; a search iteration queues G * (1 / visits + ...) re-roots: about 11 at 4096 games
 
 // the queued re-roots, on `stream` (always after a select has passed over the queued games)
 static int enqueue_advance(azh_engine *e, hipStream_t stream)
@@ -1433,8 +1525,9 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
 {
     if (iterations <= 0)
         return 0;
-    hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
-    if (enqueue_compact(e)) return -1;
+    const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
+    const dim3 tree_grid((e->P.G + TREE_WAVES - 1) / TREE_WAVES);
+    hipLaunchKernelGGL(k_tree, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, 2, two);  // select + leaf list
     // queued re-roots run on the side stream, under the tower that follows; the next tree launch waits for them
     auto side_advance = [&]() -> int {
         AZH_HIP(hipEventRecord(e->ev_sel, e->stream));
@@ -1465,8 +1558,7 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         if (rec) AZH_HIP(hipEventRecord(ev[1], e->stream));
         const int last = it + 1 == iterations;
         AZH_HIP(hipStreamWaitEvent(e->stream, e->ev_adv, 0));
-        hipLaunchKernelGGL(k_tree, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P, last ? 0 : 1);
-        if (!last && enqueue_compact(e)) return -1;
+        hipLaunchKernelGGL(k_tree, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, last ? 1 : 3, two);
         AZH_HIP(hipGetLastError());
         if (!last && side_advance()) return -1;
         if (rec) {
@@ -1540,6 +1632,14 @@ extern "C" int azh_engine_set_positions(azh_engine *e, const uint64_t *boards, c
     AZH_HIP(hipStreamSynchronize(e->stream));
     AZH_HIP(hipStreamSynchronize(e->stream2));
     const size_t G = (size_t)e->P.G;
+    // uids restart at the slot numbers: whatever the previous games left behind (undrained records, games held back
+    // for uid order) belongs to uids that are about to be reused, and is discarded with them
+    e->pending.clear();
+    e->pending_pos = 0;
+    e->held.clear();
+    e->next_uid = 0;
+    e->order_broken = false;
+    AZH_HIP(hipMemsetAsync(e->P.ring_head, 0, 8, e->stream));
     for (size_t g = 0; g < G; g++) {
         const uint64_t x = boards[2 * g] & ~TURN_BIT, o = boards[2 * g + 1];
         if (plies[g] < 0 || plies[g] >= e->P.max_plies || (x & o) || ((x | o) & (e->P.blockers | ~BOARD_MASK)) || !x || !o)
@@ -1655,8 +1755,13 @@ extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int6
         AZH_HIP(hipStreamSynchronize(e->stream));
         u64 head = 0;
         AZH_HIP(hipMemcpy(&head, e->P.ring_head, 8, hipMemcpyDeviceToHost));
-        if (head > e->P.ring_cap_words)
+        if (head > e->P.ring_cap_words) {
+            // A record or a drop marker did not fit (AZH_STAT_RING_OVERFLOW counts them): its uid will never come, and
+            // uid order would wait for it for ever.  From here on the order is given up instead of the games: what is
+            // held is handed out, and later games are handed out as they arrive.
             head = e->P.ring_cap_words;
+            e->order_broken = true;
+        }
         if (head > 0) {
             std::vector<uint32_t> host((size_t)head);
             AZH_HIP(hipMemcpy(host.data(), e->P.ring, (size_t)head * 4, hipMemcpyDeviceToHost));
@@ -1680,16 +1785,21 @@ extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int6
                 if (rec[7] == 2)
                     line.clear();  // a game that began at a loaded position: record drained and formatted like any other
                                    // (the measured path does the same work per finished game), but it is not a whole game
-                if (e->emit_by_uid)
+                if (e->emit_by_uid && !e->order_broken)
                     e->held[o.first] = std::move(line);
                 else if (!line.empty())
                     e->pending.push_back(std::move(line));
             }
+            // (belt and braces: the longest possible game, 400 plies, outlives a few generations of short ones in the
+            // other slots — not sixteen)
+            if (e->held.size() > 16 * (size_t)e->P.G + 64)
+                e->order_broken = true;
             if (e->emit_by_uid) {
-                for (auto it = e->held.begin(); it != e->held.end() && it->first == e->next_uid; it = e->held.erase(it)) {
+                for (auto it = e->held.begin(); it != e->held.end() && (e->order_broken || it->first == e->next_uid);
+                     it = e->held.erase(it)) {
                     if (!it->second.empty())
                         e->pending.push_back(std::move(it->second));
-                    e->next_uid++;
+                    e->next_uid = it->first + 1;
                 }
             }
         }

@@ -29,7 +29,7 @@ FLAG_SYMMETRY_AVG = 128    # nn_evals.py:48-62 on every evaluation
 FLAG_ONE_RANDOM_MOVE = 64  # cpp/self_play_client.cpp:515-552 (compile-time variant of the reference client)
 FLAG_EVAL_CACHE = 256      # engine.py:127-234: positions a game's search has already evaluated are not evaluated again
 STAT_NAMES = ["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
-              "edge_overflow", "reroot_nodes", "reroot_edges", "ring_overflow", "cache_hits"]
+              "edge_overflow", "reroot_nodes", "reroot_edges", "ring_overflow", "cache_hits", "parked", "reroot_spills"]
 
 
 class AzhError(RuntimeError):

@@ -174,7 +174,9 @@ typedef struct {
 enum {
     AZH_STAT_STEPS = 0, AZH_STAT_NN_EVALS, AZH_STAT_LEVELS, AZH_STAT_CHILDREN, AZH_STAT_NEW_MOVES,
     AZH_STAT_PLIES, AZH_STAT_GAMES, AZH_STAT_DROPPED, AZH_STAT_EDGE_OVERFLOW, AZH_STAT_REROOT_NODES,
-    AZH_STAT_REROOT_EDGES, AZH_STAT_RING_OVERFLOW, AZH_STAT_CACHE_HITS
+    AZH_STAT_REROOT_EDGES, AZH_STAT_RING_OVERFLOW, AZH_STAT_CACHE_HITS,
+    AZH_STAT_PARKED,        /* (game, iteration) pairs in which a descent was parked by select_budget */
+    AZH_STAT_REROOT_SPILLS  /* re-roots whose breadth-first frontier outgrew its LDS queue (the rest went through HBM) */
 };
 
 typedef struct {

@@ -25,6 +25,36 @@ def config_for(fen, visits):
                            flags=PY_ENGINE_FLAGS)
 
 
+def dirichlet_fixtures():
+    return load_gz("engine_dirichlet.json.gz")
+
+
+def dirichlet_config(rec, flags):
+    """One game slot at the fixture's position with the fixture's seed: uid 0, ply 0 — the key of the recorded draws."""
+    return orc.make_config(games=1, visits=4, seed=rec["seed"], fen_str=rec["fen"], max_plies=400, alpha=rec["alpha"],
+                           weight=rec["weight"], flags=flags)
+
+
+def check_dirichlet(rec, root, flags):
+    """Root priors after the first backup against engine.add_dirichlet_noise_to_posterior's float64 mix
+    (engine.py:117-124 == cpp/self_play_client.cpp:250-271).  With the python posterior underneath the engine and the
+    fixture compute the same expression: f32 rounding only.  The C++ generator's posterior (softmax renormalised over
+    the legal moves, no 1e-6 in the denominator) differs from engine.py's by the factor 1 + 1e-6 / legal mass, so
+    there the (1 - w) p part is compared after that factor is taken out."""
+    got = dict(root)
+    want = dict(rec["mixed"])
+    noise = dict(rec["noise"])
+    assert set(got) == set(want) == set(noise) and list(got) == [m for m, _ in rec["noise"]]
+    w = rec["weight"]
+    scale = 1.0
+    if not flags & orc.FLAG_PY_POSTERIOR:
+        scale = (1.0 - w) / sum(want[m] - w * noise[m] for m in want)   # python posterior sums to 1 / (1 + 1e-6 / mass)
+    for m in want:
+        ref = w * noise[m] + scale * (want[m] - w * noise[m])
+        assert abs(got[m] - ref) <= 4e-6 * ref + 1e-12, (m, got[m], ref)
+    assert abs(sum(got.values()) - (1.0 if scale != 1.0 else sum(want.values()))) < 2e-5
+
+
 def walk_tree(tree):
     """(boards, info, edges, moves) arena dump -> {path of UAI moves: (visits, total score, prior)} for expanded edges,
     and the root's [(uai, prior)] in movegen order."""

@@ -21,6 +21,10 @@ Writes data-only fixtures next to this script:
   engine_policy_index.json  flat index into the (7,7,17) posterior that engine.get_move_score
                           (engine.py:98-110) / add_move_to_heatmap (:80-87) use, for every clone and every jump
   engine_posterior.json.gz  NNEvaluator's posterior (engine.py:197-203) and value for 96 positions
+  engine_dirichlet.json.gz  engine.add_dirichlet_noise_to_posterior (engine.py:117-124; the mix of
+                          cpp/self_play_client.cpp:250-271) on 32 of those posteriors, alpha 0.15 / weight 0.25, with
+                          np.random.dirichlet returning a recorded vector: the normalised gamma draws the search engines
+                          make for that root (seed, uid 0, ply 0, edge j — oracle/detmath.h's gamma, in float64)
   engine_mcts.json.gz     48 deterministic searches driven exactly as uai_interface.py:44-46,79 drives them
                           (MCTSEngine.set_state + genmove(1e6, use_weighted_exponent=5.0) with MAX_STEPS = visits):
                           every edge of the final tree (path, visits, total score), root posterior, the move
@@ -172,6 +176,45 @@ def posterior_fixture():
         recs.append({"fen": b.fen(), "value": float(ev.value),
                      "posterior": [[enc(m), float(p)] for m, p in ev.posterior.items()]})
     dump_gz("engine_posterior.json.gz", recs)
+    return len(recs)
+
+
+def dirichlet_fixture():
+    """The root-noise mix.  The reference's C++ generator draws gamma(0.15) per root move, normalises and mixes
+    0.75 p + 0.25 noise (cpp/self_play_client.cpp:250-271); engine.py states the same mix as
+    add_dirichlet_noise_to_posterior (engine.py:117-124) and is importable.  Its random ingredient is replaced by a
+    recorded vector — the draws the engines under test make for this root, normalised here in float64 — so what the
+    fixture pins is the formula and which noise element meets which move."""
+    from oracle import oracle_lib as orc
+    install(distinct_on_features)
+    alpha, weight = 0.15, 0.25
+    recs = []
+    real_dirichlet = np.random.dirichlet
+    try:
+        for i, state in enumerate(sample_positions(99, 8, 10)[:96:3]):
+            b = state.copy()
+            engine.global_evaluator.populate(b)
+            posterior = b.evaluations.posterior                    # python legal_moves() order
+            seed = 5000 + i
+            order = [orc.move_string(m) for m in orc.movegen(orc.pos_from_fen(b.fen()))]   # the engines' edge order
+            assert sorted(order) == sorted(enc(m) for m in posterior)
+            gam = np.array([orc.lib().orc_probe_gamma(alpha, seed, 0, 0, j) for j in range(len(order))], dtype=np.float64)
+            noise_of = dict(zip(order, gam / gam.sum()))
+            vector = np.array([noise_of[enc(m)] for m in posterior])
+            np.random.dirichlet = lambda alphas, v=vector: (v if len(alphas) == len(v) and set(alphas) == {alpha} else None)
+            try:
+                mixed = engine.add_dirichlet_noise_to_posterior(posterior, alpha, weight)
+            except AssertionError:
+                # the reference's own sanity check (engine.py:124): with the synthetic evaluator a position with two or
+                # three legal moves can hold so little of the 833-way softmax mass that the 1e-6 of engine.py:202
+                # shows in the sum; such a position is left out
+                continue
+            recs.append({"fen": b.fen(), "seed": seed, "alpha": alpha, "weight": weight,
+                         "noise": [[m, float(noise_of[m])] for m in order],
+                         "mixed": [[enc(m), float(p)] for m, p in mixed.items()]})
+    finally:
+        np.random.dirichlet = real_dirichlet
+    dump_gz("engine_dirichlet.json.gz", recs)
     return len(recs)
 
 
@@ -477,6 +520,7 @@ def main():
     print("features:", features_fixture())
     print("policy indices:", policy_index_fixture())
     print("posteriors:", posterior_fixture())
+    print("dirichlet mixes:", dirichlet_fixture())
     recs = mcts_fixture()
     print("searches:", len(recs), "edges:", sum(len(r["edges"]) for r in recs),
           "min margin: %.3g" % min(r["min_margin"] for r in recs))

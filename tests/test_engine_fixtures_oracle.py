@@ -65,6 +65,23 @@ def test_posterior_equals_nn_evaluator():
         assert abs(sum(p for _, p in root) - sum(p for _, p in rec["posterior"])) < 1e-5
 
 
+def test_dirichlet_mix_equals_engine_py():
+    """The root-noise mix of the C++ generator (cpp/self_play_client.cpp:250-271) pinned to engine.py's statement of it
+    (engine.py:117-124), fed the engines' own normalised gamma draws."""
+    recs = fx.dirichlet_fixtures()
+    assert len(recs) >= 24
+    for flags in (orc.FLAG_PY_POSTERIOR, 0):
+        for rec in recs:
+            oe = orc.Engine(fx.dirichlet_config(rec, flags))
+            n, need = oe.select()
+            assert n == 1 and oe.game_state(0).leaf_kind == orc.LEAF_ROOT
+            logits, values = synthetic_evals_distinct(oe.leaf_boards())
+            oe.backup(logits, values)
+            _, root = fx.walk_tree(oe.tree(0))
+            fx.check_dirichlet(rec, root, flags)
+            oe.close()
+
+
 def test_search_reproduces_engine_py_trees():
     recs = fx.mcts_fixtures()
     assert len(recs) == 48

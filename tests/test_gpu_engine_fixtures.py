@@ -46,6 +46,25 @@ def test_posterior_equals_nn_evaluator():
         ge.close()
 
 
+def test_dirichlet_mix_equals_engine_py():
+    """Root priors with Dirichlet noise == engine.add_dirichlet_noise_to_posterior (engine.py:117-124, the mix of
+    cpp/self_play_client.cpp:250-271) given the engine's own normalised gamma draws — with the python posterior underneath
+    (same expression, f32 rounding) and with the C++ generator's posterior (flags 0)."""
+    recs = fx.dirichlet_fixtures()
+    assert len(recs) >= 24
+    for flags in (orc.FLAG_PY_POSTERIOR, 0):
+        for rec in recs:
+            ocfg = fx.dirichlet_config(rec, flags)
+            ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+            assert ge.select() == 1 and ge.game_state(0).leaf_kind == link.LEAF_ROOT
+            logits, values = synthetic_evals_distinct(ge.leaves()[1])
+            ge.set_evals(logits, values)
+            ge.backup()
+            _, root = fx.walk_tree(ge.tree(0))
+            fx.check_dirichlet(rec, root, flags)
+            ge.close()
+
+
 def test_search_reproduces_engine_py_trees():
     recs = fx.mcts_fixtures()
     assert len(recs) == 48

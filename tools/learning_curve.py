@@ -1,0 +1,193 @@
+#!/usr/bin/python
+"""Does the closed loop learn?  Generation -> training -> generation with the new net, then every generation against
+the first one in the arena.
+
+This script issues the three commands the reference's orchestration issues — the generator and the trainer exactly as
+looper.py:33-41 and looper.py:140-148 spell them (plus the extension flags named below), the arena as
+uai_ringmaster.py is used with two `uai_interface.py --network-path X --visits V` engines — against this repo's
+drop-in scripts, on one GPU, and writes a summary: the score of model-00k against model-001, and per generation the
+generator's own counters (dropped / edge_overflow / ring_overflow / parked share / re-root spills / cache hits) and its
+rate with the TRAINED net in the search (a trained net searches shallower and keeps larger subtrees than a random one).
+
+It is the one check of generator <-> trainer <-> arena conventions together: value sign, side to move from ply
+parity, the dists -> heat-map mapping under the 8 symmetries, batch-norm statistics in the .npy,
+blockers in self-play but not in training (Q2).  A mistake in any of them shows up as a net that does not improve.
+
+    python tools/learning_curve.py --prefix /tmp/run1 --iterations 5 --game-count 2000 --visits 400 \\
+        --training-steps 1000 --arena-games 1000 --arena-visits 100 --out gpurun_out/learning_curve.txt
+"""
+import argparse
+import json
+import os
+import re
+import signal
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def model_path(prefix, i):
+    return os.path.join(prefix, "models", "model-%03i.npy" % i)      # looper.py:67-68
+
+
+def games_path(prefix, i, process_index=0):
+    return os.path.join(prefix, "games", "model-%03i-%i.json" % (i, process_index))   # looper.py:70-74
+
+
+def count_games(path):
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        return sum(1 for line in f if line.strip())
+
+
+def log(out, text):
+    print(text)
+    sys.stdout.flush()
+    with open(out, "a") as f:
+        f.write(text + "\n")
+
+
+def generate(args, n, out):
+    """looper.generate_games (looper.py:22-65): start the generator, poll the line count, SIGTERM at --game-count."""
+    path = games_path(args.prefix, n)
+    open(path, "a").close()
+    if count_games(path) >= args.game_count:
+        log(out, "generation %d: enough games already" % n)
+        return None
+    cmd = [sys.executable, os.path.join(ROOT, "accelerated_generate_games.py"), "--network", model_path(args.prefix, n),
+           "--output-games", path, "--visits", str(args.visits)] + args.generator_flags
+    gen_log = os.path.join(args.prefix, "generator-%03i.log" % n)
+    t0 = time.time()
+    with open(gen_log, "w") as lf:
+        proc = subprocess.Popen(cmd, cwd=ROOT, stdout=lf, stderr=subprocess.STDOUT)
+        try:
+            while proc.poll() is None:
+                time.sleep(args.poll_seconds)
+                have = count_games(path)
+                print("  generation %d: %d games after %.0f s" % (n, have, time.time() - t0))
+                sys.stdout.flush()
+                if have >= args.game_count:
+                    break
+            if proc.poll() is None:
+                proc.send_signal(signal.SIGTERM)
+            rc = proc.wait(timeout=60)
+        finally:
+            if proc.poll() is None:
+                proc.kill()
+    seconds = time.time() - t0
+    text = open(gen_log).read()
+    totals = None
+    for line in text.splitlines():
+        if line.startswith("Totals: "):
+            totals = json.loads(line[len("Totals: "):])
+    if rc != 0 or totals is None:
+        log(out, "generation %d: generator exit code %s\n%s" % (n, rc, text[-3000:]))
+        raise SystemExit(2)
+    rates = [float(m.group(1)) for m in re.finditer(r"^Rate: ([0-9.]+)k evals/s", text, re.M)]
+    totals["wall_seconds"] = round(seconds, 1)
+    totals["rate_lines_k_evals_per_s"] = rates
+    return totals
+
+
+def train(args, n, out):
+    """looper.py:135-149: the window of game files and `train.py --steps S --games ... --old-path A --new-path B`."""
+    low = min(n, max(args.training_window_exclude + 1, n - args.training_window + 1))
+    paths = [games_path(args.prefix, i) for i in range(low, n + 1)]
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--steps", str(args.training_steps), "--games"] + paths + [
+        "--old-path", model_path(args.prefix, n), "--new-path", model_path(args.prefix, n + 1)]
+    t0 = time.time()
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    if res.returncode != 0:
+        log(out, "training %d -> %d failed:\n%s\n%s" % (n, n + 1, res.stdout[-3000:], res.stderr[-3000:]))
+        raise SystemExit(2)
+    losses = re.findall(r"^Step: +(\d+) -- loss: ([0-9.]+) +\(policy: ([0-9.]+) +value: ([0-9.]+)\)", res.stdout, re.M)
+    return {"games_files": [os.path.basename(p) for p in paths], "seconds": round(time.time() - t0, 1),
+            "val_loss_first": [float(x) for x in losses[0][1:]] if losses else None,
+            "val_loss_last": [float(x) for x in losses[-1][1:]] if losses else None}
+
+
+def arena(args, k, out):
+    """model-00k against model-001, every pairing both ways, through the ringmaster drop-in."""
+    eng = "python uai_interface.py --network-path %s --visits %d"
+    cmd = [sys.executable, os.path.join(ROOT, "uai_ringmaster.py"),
+           "--engine", eng % (model_path(args.prefix, k), args.arena_visits),
+           "--engine", eng % (model_path(args.prefix, 1), args.arena_visits),
+           "--game-count", str(args.arena_games), "--seed", str(args.seed + k)]
+    t0 = time.time()
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    if res.returncode != 0:
+        log(out, "arena %d failed:\n%s\n%s" % (k, res.stdout[-3000:], res.stderr[-3000:]))
+        raise SystemExit(2)
+    wins = re.findall(r"^Wins: ([0-9.]+) - ([0-9.]+) \(annulled: (\d+)\)", res.stdout, re.M)
+    a, b, ann = float(wins[-1][0]), float(wins[-1][1]), int(wins[-1][2])
+    return {"new": a, "first": b, "annulled": ann, "score": a / (a + b), "seconds": round(time.time() - t0, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    ap.add_argument("--prefix", required=True, help="run directory (models/ and games/ are created in it)")
+    ap.add_argument("--out", required=True, help="summary text file (appended to as the run proceeds)")
+    ap.add_argument("--iterations", type=int, default=5)
+    ap.add_argument("--visits", type=int, default=400)                      # looper.py:107
+    ap.add_argument("--game-count", type=int, default=2000)
+    ap.add_argument("--training-steps", type=int, default=1000)
+    ap.add_argument("--training-window", type=int, default=10)              # looper.py:111
+    ap.add_argument("--training-window-exclude", type=int, default=3)       # looper.py:112
+    ap.add_argument("--arena-games", type=int, default=1000)
+    ap.add_argument("--arena-visits", type=int, default=100)
+    ap.add_argument("--blocks", type=int, default=12)
+    ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--poll-seconds", type=float, default=10.0)             # looper.py:54
+    ap.add_argument("--generator-flags", type=str, default="--buffer-size 1024",
+                    help="extension flags appended to the generator command (one string)")
+    args = ap.parse_args()
+    args.generator_flags = args.generator_flags.split()
+    from ataxxzero_amd import model
+
+    os.makedirs(os.path.join(args.prefix, "models"), exist_ok=True)
+    os.makedirs(os.path.join(args.prefix, "games"), exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    out = args.out
+    log(out, "# learning curve: %s" % json.dumps({k: v for k, v in vars(args).items()}, sort_keys=True))
+    if not os.path.exists(model_path(args.prefix, 1)):
+        conv, bn = model.random_init(args.blocks, args.filters, seed=args.seed)
+        model.save_model(model_path(args.prefix, 1), conv, bn)
+        log(out, "model-001: random init (model.py:103-114 distributions), seed %d" % args.seed)
+
+    for n in range(1, args.iterations + 1):
+        if not os.path.exists(model_path(args.prefix, n + 1)):
+            g = generate(args, n, out)
+            if g is not None:
+                steps_per_s = g["steps"] / g["seconds"]
+                iters = g["steps"] + g["parked"]  # (game, iteration) pairs that searched: a step, or a parked descent
+                log(out, "generation %d (model-%03i plays): %d games written in %.0f s; %.3f M node-evals/s, %.3f M "
+                         "net evals/s, %.1f plies/game; dropped %d, edge_overflow %d, ring_overflow %d, parked share "
+                         "%.2f %%, re-roots %d (spilled %d, kept nodes/re-root %.1f), cache hits %.1f %% of expansions; "
+                         "levels/step %.2f, children/level %.1f" % (
+                             n, n, g["written"], g["wall_seconds"], steps_per_s * 1e-6, g["nn_evals"] / g["seconds"] * 1e-6,
+                             g["plies"] / max(1, g["games"] + g["dropped"]), g["dropped"], g["edge_overflow"],
+                             g["ring_overflow"], 100.0 * g["parked"] / max(1, iters), g["plies"], g["reroot_spills"],
+                             g["reroot_nodes"] / max(1, g["plies"]),
+                             100.0 * g["cache_hits"] / max(1, g["cache_hits"] + g["nn_evals"] - g["plies"]),
+                             g["levels"] / max(1, g["steps"]), g["children"] / max(1, g["levels"])))
+            t = train(args, n, out)
+            log(out, "training %d -> %d: %s, %.0f s; validation loss (total, policy, value) %s -> %s" % (
+                n, n + 1, " ".join(t["games_files"]), t["seconds"], t["val_loss_first"], t["val_loss_last"]))
+        else:
+            log(out, "model-%03i exists, skipping iteration %d" % (n + 1, n))
+    log(out, "")
+    log(out, "arena: model-00k vs model-001, %d games (every pairing both ways), %d visits/move" % (
+        args.arena_games, args.arena_visits))
+    for k in range(2, args.iterations + 2):
+        r = arena(args, k, out)
+        log(out, "model-%03i vs model-001: %.1f - %.1f (annulled %d) = %.1f %%   [%.0f s]" % (
+            k, r["new"], r["first"], r["annulled"], 100.0 * r["score"], r["seconds"]))
+
+
+if __name__ == "__main__":
+    main()
