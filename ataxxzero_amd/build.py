@@ -76,6 +76,34 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags, force=False):
+    """A second copy of the library compiled with extra flags (e.g. ["-DAZH_OOBZERO=0"]), for A/B runs and for the test
+    that keeps the tower's fallback build alive.  Load it with AZH_LIB=<path> in a fresh process.  Objects and library
+    live under csrc/_obj/variants/<name>/ (never shipped)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: a variant build needs the compiler")
+    out_dir = os.path.join(OBJ, "variants", name)
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libataxxzero_hip.so")
+    deps = _deps()
+    objs, procs = [], []
+    for src, extra in UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + deps):
+            procs.append((src, subprocess.Popen([hipcc] + COMMON + extra + list(extra_flags) + ["-c", s, "-o", o],
+                                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = ["%s:\n%s" % (src, out.decode(errors="replace")) for src, p in procs
+              for out in [p.communicate()[0]] if p.returncode != 0]
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
+    if force or _stale(lib, objs):
+        subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs)
+    return lib
+
+
 # Bench-only target: the reference's architecture (one host thread per game + batched evaluator) as the CPU
 # baseline bench.py times beside the GPU path.  A separate library on purpose: the product library has no CPU path.
 BASELINE_SRC = os.path.join(os.path.dirname(HERE), "tools", "cpu_baseline", "host_selfplay.hip")

@@ -34,6 +34,8 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <mutex>
 
 #include "azh_host.h"
 
@@ -584,30 +586,16 @@ __global__ __launch_bounds__(64 * (FT / 32), WPS) void k_tower(TowerArgs A)
 // A fragment: lane l holds W[oc = 16T + (l & 15)][k = 8 (l >> 4) + j]; B fragment: lane l holds
 // act[cell = 16t + (l & 15)][k = 8 (l >> 4) + j]; D: lane l holds oc = 4 (l >> 4) + reg of cell l & 15.
 #ifndef AZH_RING2
-#define AZH_RING2 2
+#define AZH_RING2 2  // A-fragment ring depth of variant 2 (steps of prefetch distance)
 #endif
 constexpr int RING2 = AZH_RING2;
-#ifndef AZH_SETPRIO
-#define AZH_SETPRIO 0
-#endif
-#ifndef AZH_PKRELU
-#define AZH_PKRELU 1   /* +1.0 % at 16 K boards, +~1 % at 3.6 K (profiles/round2_tower_variants.txt) */
-#endif
-#ifndef AZH_UNIFORM_WAVE
-#define AZH_UNIFORM_WAVE 1
-#endif
-#ifndef AZH_ROWS_LATE
-#define AZH_ROWS_LATE 1
-#endif
+// The one behavioural build switch left in the tower: off-board taps as out-of-range LDS reads (1, default; the device
+// is probed for it in azh_net_create) or steered to zero slots (0; tests/test_gpu_net.py builds and compares both).
+// The other A/B switches of round 2 (packed relu, buffer loads for the weights, first MFMA opens the accumulator,
+// late row addresses: profiles/round2_tower_variants.txt) are settled and their losing sides removed.
 #ifndef AZH_OOBZERO
 #define AZH_OOBZERO 1   /* +1.5 % at 16 K boards, +1.3 % at 3.6 K (profiles/round2_tower_variants.txt, call 9) */
 #endif
-#ifndef AZH_FIRSTC
-#define AZH_FIRSTC 1   /* +0.9 % at 16 K boards, +1.0 % at 3.6 K (profiles/round2_tower_variants.txt, call 5) */
-#endif
-#ifndef AZH_BUFFER_A
-#define AZH_BUFFER_A 1   /* with AZH_UNIFORM_WAVE: another 0.6 % at 16 K boards, ~1 % at 3.6 K (same profile) */
-#endif  // A-fragment ring depth of variant 2 (steps of prefetch distance)
 
 template <int DT> struct Mfma16;
 template <> struct Mfma16<AZH_DTYPE_BF16> {
@@ -702,7 +690,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     // Without a residual input the accumulators are not initialised at all: the first MFMA of every (A tile, cell tile)
     // takes the shift as its C operand and writes the accumulator (80 register copies per layer saved); with one they
     // start at shift + residual input.
-    const bool first_c = AZH_FIRSTC && !skip;
+    const bool first_c = !skip;
     if (!first_c) {
 #pragma unroll
         for (int t = 0; t < 4; t++)
@@ -749,7 +737,6 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
 
     // A fragments of packed step s = tap * KS + ks: [s][oc tile 8][lane][8 elements]; this wave reads tiles 4*oh .. 4*oh+3
     const unsigned lane_off = (unsigned)(lane * sizeof(afrag));
-#if AZH_BUFFER_A
     // buffer loads: resource (base of the packed weights) and the step's offset in scalar registers, the lane's 16-B
     // slot in one VGPR, the tile in the immediate — no 64-bit vector address arithmetic in the k-loop
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -761,15 +748,6 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         for (int t = 0; t < 4; t++)
             dst[t] = __builtin_bit_cast(afrag, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + t * 1024, soff, 0));
     };
-#else
-    const char *wbase = reinterpret_cast<const char *>(wp) + oh * 4096;
-    auto load_a = [&](afrag (&dst)[4], int step) {
-        const char *p = wbase + (size_t)step * 8192;
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            dst[t] = *reinterpret_cast<const afrag *>(p + t * 1024 + lane_off);
-    };
-#endif
     // (row o, inner i) -> tap = 3 dxi + dyi
     auto tap_of = [&](int o, int i) { return CHF == 0 ? 3 * o + i : 3 * i + o; };
     // packed step of walk position (row o, step j of the row); positions past the layer continue into the next
@@ -827,7 +805,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             constexpr int rs = (ring0 + j) % RING2;
             constexpr int j1 = j + 1;
             constexpr int i1 = (j1 / KS) % 3, ks1 = j1 % KS;
-            constexpr bool rows_late = AZH_ROWS_LATE && KS > 1;  // (with one k-step per tap the offsets are needed at once)
+            constexpr bool rows_late = KS > 1;  // (with one k-step per tap the offsets are needed at once)
             if constexpr (ks == 0 && !rows_late) {  // offsets of the tap after this one (it may belong to the next row)
                 const int o1 = i == 2 ? (o < 2 ? o + 1 : 2) : o;
                 rows_for(o1, IC<(i + 1) % 3>(), nxt);
@@ -844,9 +822,6 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
                 const int o1 = i == 2 ? (o < 2 ? o + 1 : 2) : o;
                 rows_for(o1, IC<(i + 1) % 3>(), nxt);
             }
-#if AZH_SETPRIO
-            __builtin_amdgcn_s_setprio(AZH_SETPRIO);  // tuning experiment (tools/tower_variants.sh): MFMA cluster at raised priority
-#endif
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 static_for<0, TPW>([&](auto ct_tag) {
@@ -857,9 +832,6 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
                         acc[t][ct] = Mfma16<DT>::mfma(a[rs][t], b[par][ct], opens ? shq[t] : acc[t][ct]);
                     }
                 });
-#if AZH_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             load_a(a[rs], step_of(o, j + RING2));
             if constexpr (ks1 == 0) {
 #pragma unroll
@@ -919,28 +891,19 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             for (int t = 0; t < 4; t++) {
                 float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < 4; i++)
                     v[i] = acc[t][ct][i];
-#if !AZH_PKRELU
-                    v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-#endif
-                }
                 f32x2 lo, hi;
                 lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
                 typedef typename Tr::pair pair;
                 const pair plo = __builtin_convertvector(lo, pair), phi = __builtin_convertvector(hi, pair);
                 uint2 packed;
-#if AZH_PKRELU
                 // relu after the conversion, on the packed pair: a negative bf16 / f16 is a negative int16, so one packed
                 // integer max with 0 clears it (conversion and relu commute: both are monotone and keep the sign)
                 typedef short short2v __attribute__((ext_vector_type(2)));
                 const short2v zero2 = {0, 0};
                 packed.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, plo), zero2));
                 packed.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, phi), zero2));
-#else
-                packed.x = __builtin_bit_cast(unsigned, plo);
-                packed.y = __builtin_bit_cast(unsigned, phi);
-#endif
 #if AZH_OOBZERO
                 *reinterpret_cast<uint2 *>(lds + cellq + G::ch_off(0, 64 * oh + 16 * t + 4 * kg)) = packed;
 #else
@@ -1039,13 +1002,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     typedef typename Tr::afrag afrag;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-#if AZH_UNIFORM_WAVE
     // the wave index is the same in all 64 lanes: say so, and everything derived from it (the weight stream's base
     // address above all) lives in scalar registers instead of being recomputed per lane
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#else
-    const int wave = tid >> 6;
-#endif
     const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
     const int tile0 = blockIdx.x * G::BOARDS;
     if (tile0 >= n)
@@ -1288,7 +1247,7 @@ static int current_device()
 // Variant 2 relies on the LDS range check: a ds_read beyond the workgroup's allocation must return zeros.  Checked once
 // per device and process before the first net is handed out (reads at 80 KiB, 160 KiB and 2^28 past a 4 KiB allocation
 // filled with ones, with and without an instruction offset): a device that answered anything else would make every
-// board edge wrong, so the library refuses to run there (rebuild with -DAZH_OOBZERO=0).
+// board edge wrong, so there the 16-bit towers run variant 1 instead (lds_range_check).
 __global__ void k_lds_range_probe(unsigned *out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1311,12 +1270,16 @@ __global__ void k_lds_range_probe(unsigned *out)
         atomicOr(out, 2u);
 }
 
-static int lds_range_check_ok()
+// 1: out-of-range LDS reads return zeros on the current device (variant 2 may run), 0: they do not (the 16-bit towers
+// fall back to variant 1, whose off-board taps read zero slots inside the allocation), < 0: the probe itself failed.
+static int lds_range_check()
 {
-    static int state[MAX_DEVICES] = {};  // 0 unknown, 1 ok, -1 failed
+    static std::mutex mu;
+    static int state[MAX_DEVICES] = {};  // 0 unknown, 1 ok, -1 failed; guarded by mu
     const int dev = current_device();
     if (dev < 0)
         return azh_fail(-4, "lds_range_check: hipGetDevice failed");
+    std::lock_guard<std::mutex> lock(mu);
     if (state[dev] == 0) {
         unsigned *d = nullptr, h = 0xFFu;
         AZH_HIP(hipMalloc((void **)&d, 4));
@@ -1329,11 +1292,11 @@ static int lds_range_check_ok()
         (void)hipFree(d);
         AZH_HIP(rc);
         state[dev] = h == 0 ? 1 : -1;
+        if (h != 0)
+            fprintf(stderr, "ataxxzero_hip: device %d does not return zeros for LDS reads beyond the workgroup's allocation; "
+                            "the 16-bit towers use the 32x32 variant here (or rebuild with -DAZH_OOBZERO=0)\n", dev);
     }
-    if (state[dev] < 0)
-        return azh_fail(-5, "this device does not return zeros for LDS reads beyond the workgroup's allocation; "
-                            "rebuild the library with -DAZH_OOBZERO=0");
-    return 0;
+    return state[dev] > 0 ? 1 : 0;
 }
 #endif
 
@@ -1350,8 +1313,8 @@ extern "C" int azh_net_create(int blocks, int filters, const float *conv_flat, c
     if (azh_require_device())
         return -3;
 #if AZH_OOBZERO
-    if (int rc = lds_range_check_ok())
-        return rc;
+    if (lds_range_check() < 0)  // probes the device once; the answer picks the tower variant in net_launch
+        return -5;
 #endif
     azh_net *net = new azh_net();
     net->blocks = blocks;
@@ -1573,7 +1536,12 @@ static int net_launch(azh_net *net, int dtype, const unsigned long long *d_board
         }
     }
     const bool six = tower_boards() == 6;
-    if (tower_variant() == 2 && dtype != AZH_DTYPE_F32) {
+    bool v2 = tower_variant() == 2 && dtype != AZH_DTYPE_F32;
+#if AZH_OOBZERO
+    if (v2 && lds_range_check() != 1)
+        v2 = false;
+#endif
+    if (v2) {
         if (d_stamps)
             return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16, true>(a, max_n, stream)
                                            : azh_fail(-2, "stamps are built for bf16 only");

@@ -171,12 +171,17 @@ def _symmetry_tables():
 
 
 _TABLES = None
+# Per-entry arrays of the batched pipeline, kept OUTSIDE the entries (they stay plain JSON data) and bounded: keyed by
+# id(entry) with the entry itself held, so an id is never reused while its row is alive; oldest rows go first.
+_ARRAYS = {}
+_ARRAYS_MAX = 100000      # entries; about 15 KB each (int8 cells, int16 indices, float32 weights)
 
 
 def _entry_arrays(entry):
-    """Per-entry arrays for the batched pipeline, built once: cells [plies][49] and, per ply, the flat policy indices
-    and weights of its target (the visit distribution, or the move played)."""
-    cache = entry.get("_arrays")
+    """Per-entry arrays for the batched pipeline, built on first use: cells [plies][49] and, per ply, the flat policy
+    indices and weights of its target (the visit distribution, or the move played)."""
+    row = _ARRAYS.get(id(entry))
+    cache = row[1] if row is not None and row[0] is entry else None
     if cache is None:
         cells = np.asarray(entry["boards"], dtype=np.int8)
         probe = np.zeros((BOARD, BOARD, MOVE_TYPES))
@@ -198,8 +203,12 @@ def _entry_arrays(entry):
                 idx.append(int(np.flatnonzero(probe.ravel())[0]))
                 wts.append(w)
             start.append(len(idx))
-        cache = entry["_arrays"] = (cells, np.asarray(idx, dtype=np.int64), np.asarray(wts, dtype=np.float64),
-                                    np.asarray(start, dtype=np.int64))
+        cache = (cells, np.asarray(idx, dtype=np.int16), np.asarray(wts, dtype=np.float32),
+                 np.asarray(start, dtype=np.int32))
+        if len(_ARRAYS) >= _ARRAYS_MAX:
+            for key in list(_ARRAYS)[:_ARRAYS_MAX // 10]:
+                del _ARRAYS[key]
+        _ARRAYS[id(entry)] = (entry, cache)
     return cache
 
 
@@ -237,7 +246,7 @@ def make_minibatch(entries, size):
     feats[..., 1] = shown == movers
     feats[..., 2] = (shown != 0) & (shown != movers)
     pols = np.zeros((size, BOARD * BOARD * MOVE_TYPES), dtype=np.float32)
-    np.add.at(pols, (np.concatenate(rows), np.concatenate(pidx)), np.concatenate(pw).astype(np.float32))
+    np.add.at(pols, (np.concatenate(rows), np.concatenate(pidx)), np.concatenate(pw))
     if (np.abs(1 - pols.sum(axis=1)) >= 1e-3).any():
         raise AssertionError("policy target does not sum to one")
     vals = np.where(np.asarray(results)[:, None] == movers, 1, -1).astype(np.float32)

@@ -177,24 +177,30 @@ def spread(sp, args, seed):
     return {"mean_ply": float(plies[pick].mean()), "source": SNAPSHOT}
 
 
-def target_leg(conv, bn, args, games=16384, steps=2, warmup=1, flags=0):
+def target_leg(conv, bn, args, games=16384, steps=2, warmup=1, flags=0, dtype=None, select_budget=None):
     """Another operating point measured the same way as the headline and reported beside it (never as `value`):
-    BASELINE.json's north-star point (>= 10k concurrent games on one GPU, 400 sims/move), or the headline workload with the
-    evaluation cache on."""
+    BASELINE.json's north-star point (>= 10k concurrent games on one GPU, 400 sims/move), the headline workload with the
+    evaluation cache on (the generator CLI's default), or with the f16 tower."""
     from ataxxzero_amd import model, selfplay
-    sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=args.dtype, seed=selfplay.DEFAULT_SEED + 77,
-                           select_budget=args.select_budget, flags=flags)
+    dtype = dtype or args.dtype
+    budget = args.select_budget if select_budget is None else select_budget
+    sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=dtype, seed=selfplay.DEFAULT_SEED + 77,
+                           select_budget=budget, flags=flags)
     try:
         spread(sp, args, selfplay.DEFAULT_SEED + 77)
         d, finished, dt, tm, _ = measure(sp, args, steps, warmup)
         it = max(tm["iterations"], 1)
         iters = steps * args.iters_per_step
         tf = d["nn_evals"] / float(iters) * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] / it * 1e-3) / 1e12
-        return {"games": games, "node_evals_per_s": d["steps"] / dt, "nn_evals_per_s": d["nn_evals"] / dt,
+        tree_ms = (tm["select_ms"] + tm["backup_ms"]) / it
+        tree_gbs = tree_bytes(d) / float(iters) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+        return {"games": games, "dtype": dtype, "eval_cache": bool(flags), "select_budget": budget,
+                "node_evals_per_s": d["steps"] / dt, "nn_evals_per_s": d["nn_evals"] / dt,
                 "cache_hits_per_s": d.get("cache_hits", 0) / dt, "plies_per_s": d["plies"] / dt, "games_per_s": d["games"] / dt,
                 "ms_per_iteration": 1e3 * dt / iters, "steps": steps,
-                "tower_ms_per_launch": tm["net_ms"] / it, "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[args.dtype],
-                "tree_ms_per_iteration": (tm["select_ms"] + tm["backup_ms"]) / it}
+                "tower_ms_per_launch": tm["net_ms"] / it, "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[dtype],
+                "tree_ms_per_iteration": tree_ms, "tree_roofline_frac": tree_gbs / HBM_PEAK_GBS,
+                "parked_share": d.get("parked", 0) / float(max(1, d.get("parked", 0) + d["steps"]))}
     finally:
         sp.close()
 
@@ -349,8 +355,9 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": launch_ms, "evals_per_launch": evals_per_launch,
                          "launches_timed": it, "launches_in_region": iters * args.streams, "flops_per_eval": flops},
-            "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup + move-due mark + select, fused) + k_compact on the engine's stream; "
-                                         "k_advance_list (re-roots) runs on a side stream under the tower",
+            "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup + move-due mark + select + leaf-list compaction, one launch, four games per "
+                                         "workgroup) on the engine's stream; k_advance_list (re-roots) on a high-priority side "
+                                         "stream under the tower",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS,
                               "tree_phase_ms_per_iteration": tree_ms,
                               "bytes_per_step": tree_bytes(d) / float(max(d["steps"], 1)),
@@ -362,10 +369,16 @@ def main():
         if group.world == 1 and not args.no_target_leg and args.streams == 1:
             out["target_10k_games"] = target_leg(conv, bn, args)
             if not args.eval_cache:
-                # the same workload with AZH_FLAG_EVAL_CACHE: MCTS steps/s and games/s rise, net evaluations/s do not (the
-                # headline keeps the C++ generator's rule: every new node goes to the net)
+                # the same workload with AZH_FLAG_EVAL_CACHE (the generator CLI's default): MCTS steps/s and games/s rise,
+                # net evaluations/s do not (the headline keeps the C++ generator's rule: every new node goes to the net)
                 out["with_eval_cache"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2,
-                                                    flags=link.FLAG_EVAL_CACHE)
+                                                    flags=link.FLAG_EVAL_CACHE, select_budget=64)
+                out["target_10k_games_with_eval_cache"] = target_leg(conv, bn, args, flags=link.FLAG_EVAL_CACHE,
+                                                                     select_budget=64)
+            if args.dtype == "bf16":
+                # the f16 tower on the headline workload: closer to the f32 search than bf16 (profiles/
+                # round2_precision_in_the_loop.json: top-1 100 % / TV 0.02 % vs 98.4 % / 1.7 %); BASELINE names bf16
+                out["with_f16"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2, dtype="f16")
         if group.world == 1 and not args.no_gemm_ceiling:
             out["roofline"]["vendor_gemm_on_this_box"] = vendor_gemm_ceiling()
         if group.world == 1 and not args.no_cpu_baseline:

@@ -78,6 +78,25 @@ def test_bench_py_starts_its_own_ranks_and_aggregates():
     assert out["seeds"] == [20260101, 20260102]
 
 
+def test_bench_py_eight_ranks_as_the_scaling_run_starts_them():
+    """The rank count the round-end scaling run ends with: `bench.py --gpus 8` starts eight processes, eight distinct Philox
+    seeds, one aggregate line with n_gpus 8 (units summed, max-over-ranks time).  The GPU work is replaced by fixed
+    units: a GPU box admits six processes on its card, so the eight-process launch itself is rehearsed here, and the
+    GPU side of a many-rank launch with five ranks in tests/test_gpu_cli.py."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plumbing-selftest"],
+                         env=env, capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["units_total"] == 1000.0 * 36 and out["t_max"] == 8.0
+    assert out["seeds"] == [20260101 + r for r in range(8)]
+    print("8-rank launch, rendezvous and teardown: %.1f s wall" % (time.time() - t0))
+
+
 def test_bench_py_under_the_launcher_the_driver_uses():
     """The round-end scaling run starts bench.py as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: the ranks read RANK / LOCAL_RANK / WORLD_SIZE /

@@ -349,6 +349,66 @@ def test_bench_py_two_ranks_on_one_gpu():
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["launches_timed"] > 0
 
 
+# A GPU box admits six processes on its card at once, this test process included: five ranks is the largest many-rank
+# launch that can be rehearsed on the GPU (the eight-process launch itself: tests/test_distrib_gloo.py).
+MANY_RANKS = 5
+
+
+def test_bench_py_many_ranks_on_one_gpu():
+    """The launch the round-end scaling run makes, with as many ranks as one GPU box admits: `bench.py --gpus 5` spawns
+    its ranks, every rank builds its own engine and net on the (shared) GPU with its own Philox stream, they meet over
+    gloo, rank 0 prints ONE line with the job's aggregate; a dying rank would fail the run (test_distrib_gloo.py)."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(AZH_DEVICE_MOD="1", AZH_DIST_BACKEND="gloo")
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(MANY_RANKS), "--games", "512",
+                          "--steps", "4", "--warmup", "1", "--iters-per-step", "60", "--visits", "32", "--blocks", "2",
+                          "--phase-fill", "60", "--no-cpu-baseline", "--no-target-leg", "--no-gemm-ceiling"], env=env, cwd=ROOT,
+                         capture_output=True, timeout=900)
+    wall = time.time() - t0
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == MANY_RANKS and out["steps"] == 4 and out["scaling"] == "weak" and out["value"] > 0
+    total_steps = out["value"] * out["ms_per_step"] * 4e-3
+    assert 0.8 * MANY_RANKS < total_steps / out["counters"]["steps"] < 1.2 * MANY_RANKS   # every rank's shard is in the sum
+    assert total_steps <= MANY_RANKS * 512 * 240
+    print("%d ranks on one GPU: %.1f s wall for a %.2f s timed region (import + rendezvous + engine set-up dominate)"
+          % (MANY_RANKS, wall, out["ms_per_step"] * 4e-3))
+
+
+def test_generator_processes_side_by_side_write_distinct_games(tmp_path):
+    """looper.py --parallel-games-processes N (looper.py:33-41,70-74): N generator processes on model-%03i-{0..N-1}.json.
+    The file index picks the GPU (folded onto this box's one) and the Philox stream; every file gets its own games."""
+    import time
+    conv, bn = model.random_init(2, 128, seed=6)
+    net_path = str(tmp_path / "model-001.npy")
+    model.save_model(net_path, conv, bn)
+    paths = [str(tmp_path / ("model-001-%d.json" % i)) for i in range(MANY_RANKS)]
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "accelerated_generate_games.py"), "--network", net_path,
+                               "--output-games", p, "--visits", "8", "--buffer-size", "64", "--seed", "100",
+                               "--emit-order", "finish", "--max-seconds", "25"], cwd=ROOT, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for p in paths]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, text in zip(procs, outs):
+        assert p.returncode == 0, text[-2000:]
+        assert "Totals: " in text and "ring_overflow 0" in text
+    games = [[l for l in open(p) if l.strip()] for p in paths]
+    assert all(len(g) >= 20 for g in games), [len(g) for g in games]
+    seen = set()
+    for g in games:
+        assert len(set(g)) == len(g)           # no game twice in a file
+        assert not (seen & set(g))             # and none shared between the files: distinct streams (seed + index)
+        seen |= set(g)
+    seeds = [int(next(l for l in t.splitlines() if l.startswith("Philox seed:")).split(":")[1]) for t in outs]
+    assert seeds == [100] * MANY_RANKS         # the same --seed everywhere: the process index is what separates them
+    print("%d generator processes side by side: %.1f s wall, games per file %s" % (MANY_RANKS, time.time() - t0,
+                                                                                     [len(g) for g in games]))
+
+
 def test_bench_py_rank_over_rccl():
     """What every rank of an N > 1 run does, rehearsed with one rank (AZH_DIST_FORCE=1): torch's HIP runtime and the
     RCCL communicator come up first (init_process_group("nccl") + a device barrier), this package's library second,

@@ -97,14 +97,15 @@ def test_leaf_features_are_reference_rows():
         ge.backup()
 
 
-def test_device_resident_selfplay_with_builtin_net():
+@pytest.mark.parametrize("dtype,visits", [("bf16", 24), ("f16", 100)])
+def test_device_resident_selfplay_with_builtin_net(dtype, visits):
     conv, bn = model.random_init(2, 128, seed=2)
     net = link.Net(conv, bn)
-    ocfg = orc.make_config(64, 24, seed=11, max_plies=400)
+    ocfg = orc.make_config(64, visits, seed=11, max_plies=400)
     ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
     lines = []
-    for _ in range(40):
-        ge.run(net, 200, link.DTYPE_BF16)
+    for _ in range(10 * visits):
+        ge.run(net, 200, link.DTYPES[dtype])
         lines += ge.drain_json()
         if len(lines) >= 40:
             break
@@ -230,31 +231,41 @@ def test_parked_descents_match_oracle_and_leave_every_game_unchanged():
     assert set(g_lines) <= set(lines0)
 
 
-def test_full_size_workload_invariants():
-    """BASELINE's full size (4096 games, 400 sims/move, 12x128 bf16, level budget 48) is checked through
-    size-independent properties of the search: tree bookkeeping identities on sampled games, counter identities over
-    the whole batch, and replay of every game written."""
-    conv, bn = model.random_init(12, 128, seed=1)
+@pytest.mark.parametrize("name,visits,blocks,net_seed,dtype,flags", [
+    ("C3-shard", 400, 12, 1, "bf16", 0),            # BASELINE configs[2]'s per-GPU shard = the bench's workload
+    ("C2", 200, 12, 1, "bf16", 0),                  # configs[1]: 4096 games, 200 sims, 12x128, bf16
+    ("C4", 800, 8, 3, "f16", 0),                    # configs[3]: 8x128, fp16, 800 sims (node_cap 808)
+    ("C3-shard-cached", 400, 12, 1, "bf16", link.FLAG_EVAL_CACHE),   # the generator CLI's default mode
+])
+def test_full_size_workload_invariants(name, visits, blocks, net_seed, dtype, flags):
+    """BASELINE's full sizes (4096 games; 200 / 400 / 800 sims/move; 12x128 bf16 and 8x128 f16; level budget 48 or 64)
+    are checked through size-independent properties of the search: tree bookkeeping identities on sampled games, counter
+    identities over the whole batch, and replay of the games written."""
+    conv, bn = model.random_init(blocks, 128, seed=net_seed)
     net = link.Net(conv, bn)
-    G, V = 4096, 400
-    ocfg = orc.make_config(G, V, seed=20260101, select_budget=48)
+    G, V = 4096, visits
+    DT = link.DTYPES[dtype]
+    ocfg = orc.make_config(G, V, seed=20260101, select_budget=64 if flags else 48, flags=flags)
     ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+    assert ge.node_cap == V + 8
     ge.set_visits(16)
     lines = []
     for _ in range(6):
-        ge.run(net, 250, link.DTYPE_BF16)
+        ge.run(net, 250, DT)
         lines += ge.drain_json()
     ge.set_visits(V)
     for _ in range(4):
-        ge.run(net, 250, link.DTYPE_BF16)
+        ge.run(net, 250, DT)
         lines += ge.drain_json()
     ge.sync()
     st = ge.stats()
     assert st["edge_overflow"] == 0 and st["ring_overflow"] == 0
-    assert st["games"] == len(lines) > 1000
+    assert st["games"] == len(lines) > 500
+    assert (st["cache_hits"] > 0) == bool(flags) and st["parked"] > 0
     # every step is one descent that ends in an evaluation or a terminal re-hit; evaluations = steps that reached a new
     # non-terminal node + one root (re-)evaluation per ply and per game start
-    assert st["steps"] <= 2500 * G and st["nn_evals"] <= st["steps"] + st["plies"] + st["games"] + st["dropped"] + G
+    assert st["steps"] + st["parked"] <= 2500 * G
+    assert st["nn_evals"] + st["cache_hits"] <= st["steps"] + st["plies"] + st["games"] + st["dropped"] + G
     assert st["levels"] >= st["steps"]  # every descent looks at the root at least
     rng = np.random.default_rng(0)
     for g in rng.choice(G, size=48, replace=False):

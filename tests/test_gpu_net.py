@@ -74,6 +74,49 @@ def test_other_filter_counts(filters, blocks, n):
         link.Net(*model.random_init(1, 96, seed=1))   # only 64 / 128 / 256 are built
 
 
+def test_zero_slot_build_of_the_tower_equals_the_default_bit_for_bit(tmp_path):
+    """The default 16-bit tower reads off-board taps as out-of-range LDS addresses (AZH_OOBZERO=1: the hardware's range
+    check supplies the zeros; probed per device).  Its escape hatch — the -DAZH_OOBZERO=0 build, off-board taps steered to
+    zero slots inside the allocation — is compiled here and must give the same bits on the same boards, bf16 and f16:
+    the two differ only in WHERE a zero is read."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from ataxxzero_amd import build
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this box")
+    lib = build.build_variant("oobzero0", ["-DAZH_OOBZERO=0"])
+    assert os.path.exists(lib) and os.path.abspath(lib) != os.path.abspath(link.library_path())
+    conv, bn = model.random_init(3, 128, seed=41, perturb_bn=True)
+    lb = sample_leaf_boards(200, 12, BLOCK4_MASK)   # 66 full workgroups and a partial one
+    weights, boards, out = str(tmp_path / "w.npy"), str(tmp_path / "boards.npy"), str(tmp_path / "out.npz")
+    model.save_model(weights, conv, bn)
+    np.save(boards, lb)
+    script = ("import sys, numpy as np\n"
+              "sys.path.insert(0, %r)\n"
+              "from ataxxzero_amd import link, model\n"
+              "assert link.library_path() != %r and link.load()._name == %r\n"
+              "net = link.Net(*model.load_model(%r))\n"
+              "lb = np.load(%r)\n"
+              "res = {}\n"
+              "for name, dt in (('bf16', link.DTYPE_BF16), ('f16', link.DTYPE_F16)):\n"
+              "    p, v = net.forward(lb, %d, dt)\n"
+              "    res[name + '_p'], res[name + '_v'] = p, v\n"
+              "np.savez(%r, **res)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), lib, lib, weights,
+                                          boards, BLOCK4_MASK, out)
+    env = dict(os.environ, AZH_LIB=lib)
+    res = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, timeout=600)
+    assert res.returncode == 0, res.stdout.decode()[-2000:] + res.stderr.decode()[-2000:]
+    other = np.load(out)
+    net = link.Net(conv, bn)
+    for name, dt in (("bf16", link.DTYPE_BF16), ("f16", link.DTYPE_F16)):
+        p, v = net.forward(lb, BLOCK4_MASK, dt)
+        assert np.abs(p).max() > 1e-3
+        assert (p.view(np.uint32) == other[name + "_p"].view(np.uint32)).all(), name
+        assert (v.view(np.uint32) == other[name + "_v"].view(np.uint32)).all(), name
+
+
 def test_first_boards_of_partial_tiles_and_empty_batch():
     conv, bn = model.random_init(1, 128, seed=4, perturb_bn=True)
     net = link.Net(conv, bn)
