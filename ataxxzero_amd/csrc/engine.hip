@@ -43,6 +43,9 @@ constexpr int NSTAT = AZH_STAT_COUNT;
 constexpr int BFS_QL = 384;  // re-root frontier entries kept in LDS; later ones spill to bfs_spill in HBM
 constexpr int TREE_WAVES = 4;  // games (one wave each) per workgroup of the fused tree kernel
 constexpr int TREE_THREADS = TREE_WAVES * WAVE;
+// stamps of the diagnostic k_tree<true> (azh_engine_tree_stamps): wave start, state loaded, backup done, mark done,
+// descent done (leaf edge chosen / parked / terminal), expansion done, state stored, workgroup done (all four games)
+constexpr int TREE_STAMPS = 8;
 
 struct EngineParams {
     int G, visits, node_cap, edge_cap, path_cap, max_plies;
@@ -74,6 +77,7 @@ struct EngineParams {
     int *leaf_list2;   // arena: leaves of the games whose mover is net B
     int *leaf_count2;
     int *tree_done;    // tickets of the workgroups of a k_tree launch (the last one compacts the leaf list)
+    u64 *stamps;       // diagnostic instantiation of k_tree only: [G][TREE_STAMPS] s_memtime readings (100 MHz)
     float *logits;
     float *values;
     u32 *rec;
@@ -96,6 +100,15 @@ struct TreeLds {
 // All G waves of a launch must be resident at once (the kernel lasts as long as its deepest descent):
 // 16 games per CU at G = 4096, so the scratch has to stay under 160 KiB / 16.
 static_assert(sizeof(TreeLds) <= 8192, "TreeLds: keep >= 20 game waves per CU");
+
+__device__ inline u64 tree_stamp()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the phase's memory operations are part of the phase
+    const u64 t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 
 struct Arena {
     ulonglong2 *nb;
@@ -257,7 +270,8 @@ __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
 // ------------------------------------------------------------------ select + expand
 
 // `s` is the game's state, held in registers by the caller (the same values in all 64 lanes); written back here.
-__device__ inline void select_game(const EngineParams &P, int g, azh_game_state &s, u16 *s_moves)
+template <bool STAMP = false>
+__device__ inline void select_game(const EngineParams &P, int g, azh_game_state &s, u16 *s_moves, u64 *st = nullptr)
 {
     const int lane = lane_id();
     Arena A = arena_of(P, s.arena, g);
@@ -414,6 +428,7 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
             sel_eidx = eidx;
             }
             // expand (:429-439)
+            if constexpr (STAMP) st[4] = tree_stamp();
             const u32 eidx = sel_eidx;
             const u32 mv = A.em[eidx];
             const ulonglong2 pw = A.nb[node];
@@ -484,6 +499,11 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
     s.leaf_kind = kind;
     s.leaf_node = leaf_node;
     s.path_len = depth;
+    if constexpr (STAMP) {
+        st[5] = tree_stamp();
+        if (st[4] == 0)
+            st[4] = st[5];  // no expansion: the descent ended at a finished position, parked, or there was none
+    }
     if (lane == 0) {
         P.gs[g] = s;
         int need = (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) ? 1 : 0;
@@ -1145,6 +1165,7 @@ __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt
 // the next select, with the game's state in registers throughout; TREE_WAVES games share a workgroup (each wave on
 // its own: wave_sync, never a workgroup barrier, inside a game), and the last workgroup to finish compacts the leaf
 // list.  mode bit 0: backup + mark, bit 1: select (+ compaction).
+template <bool STAMP>
 __global__ __launch_bounds__(TREE_THREADS) void k_tree(EngineParams P, int mode, int two)
 {
     __shared__ u16 s_moves[TREE_WAVES][MAX_MOVES];  // per game: the move list of the node being expanded
@@ -1152,22 +1173,41 @@ __global__ __launch_bounds__(TREE_THREADS) void k_tree(EngineParams P, int mode,
     __shared__ int s_last;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the game's addresses are scalars
     const int g = blockIdx.x * TREE_WAVES + w;
+    u64 st[TREE_STAMPS] = {};
+    if constexpr (STAMP) st[0] = tree_stamp();
     if (g < P.G) {
         azh_game_state s = P.gs[g];
         const int forced = P.force[g];  // (same round trip as the state)
+        if constexpr (STAMP) st[1] = tree_stamp();
         if (mode & 1) {
             backup_game(P, g, s);
+            if constexpr (STAMP) st[2] = tree_stamp();
             mark_game(P, g, s, forced);
         }
+        if constexpr (STAMP) {
+            st[3] = tree_stamp();
+            if (!(mode & 1)) st[2] = st[3];
+        }
         if (mode & 2)
-            select_game(P, g, s, s_moves[w]);  // stores the state
+            select_game<STAMP>(P, g, s, s_moves[w], st);  // stores the state
         else if (lane_id() == 0)
             P.gs[g] = s;
     }
     if (!(mode & 2))
         return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's flag has left the CU
+    if constexpr (STAMP) st[6] = tree_stamp();
     __syncthreads();
+    if constexpr (STAMP) {
+        st[7] = tree_stamp();
+        if (g < P.G && lane_id() < TREE_STAMPS) {
+            u64 v = st[0];
+#pragma unroll
+            for (int k = 1; k < TREE_STAMPS; k++)
+                v = lane_id() == k ? st[k] : v;
+            P.stamps[(size_t)g * TREE_STAMPS + lane_id()] = v;
+        }
+    }
     if (threadIdx.x == 0)
         s_last = __hip_atomic_fetch_add(P.tree_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
@@ -1249,6 +1289,7 @@ struct azh_engine {
     int *h_count = nullptr;  // pinned
     bool selected = false;
     bool arena_lists = false;  // run_arena: one leaf list per net
+    bool stamp_next = false;   // azh_engine_tree_stamps: the next fused tree launch of the loop is the stamped instantiation
 };
 
 static const size_t MAX_TIMED_SAMPLES = 8192;
@@ -1527,7 +1568,7 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         return 0;
     const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
     const dim3 tree_grid((e->P.G + TREE_WAVES - 1) / TREE_WAVES);
-    hipLaunchKernelGGL(k_tree, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, 2, two);  // select + leaf list
+    hipLaunchKernelGGL(k_tree<false>, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, 2, two);  // select + leaf list
     // queued re-roots run on the side stream, under the tower that follows; the next tree launch waits for them
     auto side_advance = [&]() -> int {
         AZH_HIP(hipEventRecord(e->ev_sel, e->stream));
@@ -1558,7 +1599,12 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         if (rec) AZH_HIP(hipEventRecord(ev[1], e->stream));
         const int last = it + 1 == iterations;
         AZH_HIP(hipStreamWaitEvent(e->stream, e->ev_adv, 0));
-        hipLaunchKernelGGL(k_tree, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, last ? 1 : 3, two);
+        if (e->stamp_next && !last) {
+            hipLaunchKernelGGL(k_tree<true>, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, 3, two);
+            e->stamp_next = false;
+        } else {
+            hipLaunchKernelGGL(k_tree<false>, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, last ? 1 : 3, two);
+        }
         AZH_HIP(hipGetLastError());
         if (!last && side_advance()) return -1;
         if (rec) {
@@ -1592,6 +1638,30 @@ extern "C" int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_
     const int rc = run_loop(e, net_a, net_b, dtype, iterations);
     e->arena_lists = false;
     return rc;
+}
+
+// Diagnostic: two search iterations of the device loop, the tree launch between the two towers being the stamped
+// instantiation of k_tree; out [games][8] u64 = s_memtime readings (100 MHz) per game: wave start, state loaded, backup
+// done, mark done, descent done, expansion done, state stored, workgroup done.
+extern "C" int azh_engine_tree_stamps(azh_engine *e, azh_net *net, int dtype, uint64_t *out)
+{
+    if (!e || !net || !out)
+        return azh_fail(-1, "azh_engine_tree_stamps: null argument");
+    if (!e->P.stamps) {
+        void *q = nullptr;
+        AZH_HIP(hipMalloc(&q, (size_t)e->P.G * TREE_STAMPS * 8));
+        e->allocs.push_back(q);
+        e->P.stamps = (u64 *)q;
+    }
+    AZH_HIP(hipMemsetAsync(e->P.stamps, 0, (size_t)e->P.G * TREE_STAMPS * 8, e->stream));
+    e->stamp_next = true;
+    const int rc = run_loop(e, net, nullptr, dtype, 2);
+    e->stamp_next = false;
+    if (rc)
+        return rc;
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    AZH_HIP(hipMemcpy(out, e->P.stamps, (size_t)e->P.G * TREE_STAMPS * 8, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // Root-visit threshold for the coming moves (1 .. the value the engine was created with; the

@@ -96,6 +96,7 @@ SIGNATURES = {
     "azh_engine_game_state": (ctypes.c_int, [_vp, ctypes.c_int, _P(GameState)]),
     "azh_engine_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "azh_engine_stats": (ctypes.c_int, [_vp, _vp]),
+    "azh_engine_tree_stamps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
     "azh_engine_timing_reset": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_timing": (ctypes.c_int, [_vp, _P(Timing)]),
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
@@ -377,6 +378,12 @@ class Engine:
         out = np.zeros(STAT_COUNT, dtype=np.uint64)
         check(load().azh_engine_stats(self.h, _ptr(out)))
         return {n: int(out[i]) for i, n in enumerate(STAT_NAMES)}
+
+    def tree_stamps(self, net, dtype=DTYPE_BF16):
+        """(G, 8) s_memtime readings (100 MHz) of one stamped tree launch of the device loop (two iterations are run)."""
+        out = np.zeros((self.G, 8), dtype=np.uint64)
+        check(load().azh_engine_tree_stamps(self.h, net.h, dtype, _ptr(out)))
+        return out
 
     def timing_reset(self, enable=True):
         """False / 0: off; True / 1: every iteration of the device loop is event-timed; n: every n-th."""

@@ -398,11 +398,11 @@ def test_generator_processes_side_by_side_write_distinct_games(tmp_path):
         assert "Totals: " in text and "ring_overflow 0" in text
     games = [[l for l in open(p) if l.strip()] for p in paths]
     assert all(len(g) >= 20 for g in games), [len(g) for g in games]
-    seen = set()
-    for g in games:
-        assert len(set(g)) == len(g)           # no game twice in a file
-        assert not (seen & set(g))             # and none shared between the files: distinct streams (seed + index)
-        seen |= set(g)
+    # distinct streams (seed + file index): two processes on one stream would write the same games.  Only games long
+    # enough to be unlikely twice by chance count (at 8 visits a six-ply game does repeat): lines over 15 kB, 60+ plies
+    long_games = [l for g in games for l in g if len(l) > 15000]
+    assert len(long_games) > 100 and len(json.loads(long_games[0])["moves"]) >= 60
+    assert len(set(long_games)) == len(long_games)
     seeds = [int(next(l for l in t.splitlines() if l.startswith("Philox seed:")).split(":")[1]) for t in outs]
     assert seeds == [100] * MANY_RANKS         # the same --seed everywhere: the process index is what separates them
     print("%d generator processes side by side: %.1f s wall, games per file %s" % (MANY_RANKS, time.time() - t0,

@@ -4,11 +4,15 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_trace
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# a step is 250 search iterations: keep the trace to a few thousand launches, and keep bench.py's child processes (the
+# vendor-GEMM leg) and extra legs out of it — a child inherits the profiler and writes a trace of its own
+ARGS=${ARGS:---steps 6 --warmup 2 --no-target-leg --no-gemm-ceiling}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu-baseline ${ARGS} > $OUT/log.txt 2>&1
 cd $R
 python3 - <<PY
 import csv,glob,collections
-f=glob.glob("gpurun_out/prof_trace/*/*_kernel_trace.csv")[0]
+import os
+f=max(glob.glob("gpurun_out/prof_trace/*/*_kernel_trace.csv"), key=os.path.getsize)   # the bench process, not a helper's
 rows=list(csv.DictReader(open(f)))
 by=collections.defaultdict(list)
 for r in rows: by[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
