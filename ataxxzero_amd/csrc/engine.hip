@@ -16,10 +16,10 @@
 // HBM layout (per game, two ping-pong arenas so re-rooting compacts by copying):
 //   node_board [2][G][node_cap]  16 B  x stones | turn<<63, o stones
 //   node_info  [2][G][node_cap]  16 B  first_edge, n_edges | result<<16, -, terminal value
-//   edge       [2][G][edge_cap]  16 B  prior f32, visits u32, total score f32, child u32
+//   edge       [2][G][edge_cap]  16 B  prior f32 | total score f32 | visits u16, child node u16 | the child's edge
+//                                       range: first_edge (23 bits), n_edges (8 bits), finished (1 bit) — a derived
+//                                       copy of the child's node_info, so a PUCT level is ONE 16-byte load per child
 //   edge_move  [2][G][edge_cap]   2 B  from | to<<8
-//   edge_kid   [2][G][edge_cap]   8 B  the child's (first_edge, n_edges | result<<16): derived
-//                                       copy of its node_info, so a PUCT level is ONE memory round trip
 // A node's children are one contiguous edge range, so PUCT reads them with a
 // single coalesced 16-byte-per-lane load; children are bump-allocated by the one
 // wave that owns the game (no atomics inside a tree).
@@ -45,7 +45,7 @@ constexpr int TREE_WAVES = 4;  // games (one wave each) per workgroup of the fus
 constexpr int TREE_THREADS = TREE_WAVES * WAVE;
 // stamps of the diagnostic k_tree<true> (azh_engine_tree_stamps): wave start, state loaded, backup done, mark done,
 // descent done (leaf edge chosen / parked / terminal), expansion done, state stored, workgroup done (all four games)
-constexpr int TREE_STAMPS = 8;
+constexpr int TREE_STAMPS = 10;  // + [8] levels descended, [9] children scanned in this launch
 
 struct EngineParams {
     int G, visits, node_cap, edge_cap, path_cap, max_plies;
@@ -69,7 +69,6 @@ struct EngineParams {
     uint4 *node_info;
     uint4 *edge;
     u16 *edge_move;
-    uint2 *edge_kid;
     ulonglong2 *leaf_board;
     int *need_eval;
     int *leaf_list;
@@ -77,7 +76,7 @@ struct EngineParams {
     int *leaf_list2;   // arena: leaves of the games whose mover is net B
     int *leaf_count2;
     int *tree_done;    // tickets of the workgroups of a k_tree launch (the last one compacts the leaf list)
-    u64 *stamps;       // diagnostic instantiation of k_tree only: [G][TREE_STAMPS] s_memtime readings (100 MHz)
+    u64 *stamps;       // diagnostic instantiation of k_tree only: [G][TREE_STAMPS] s_memrealtime readings (100 MHz)
     float *logits;
     float *values;
     u32 *rec;
@@ -85,7 +84,7 @@ struct EngineParams {
     u64 ring_cap_words;
     u64 *ring_head;
     u64 *stats;
-    u32 *bfs_spill;  // [G][4][node_cap] frontier entries beyond BFS_QL
+    u32 *bfs_spill;  // [G][3][node_cap] frontier entries beyond BFS_QL
 };
 
 // Per-block (= per-game wave) LDS scratch shared by the tree phases.
@@ -94,7 +93,7 @@ struct TreeLds {
     u32 old[WAVE], pref[WAVE + 1];
     union {              // the sampling weights are dead before the re-root copy starts
         u64 w[MAX_MOVES];
-        u32 q[4][BFS_QL];  // frontier queue: old node id, old first edge, n_edges | result << 16, parent edge
+        u32 q[3][BFS_QL];  // frontier queue: old node id, the node's packed edge range (old arena), parent edge (new arena)
     };
 };
 // All G waves of a launch must be resident at once (the kernel lasts as long as its deepest descent):
@@ -105,7 +104,7 @@ __device__ inline u64 tree_stamp()
 {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the phase's memory operations are part of the phase
-    const u64 t = __builtin_amdgcn_s_memtime();
+    const u64 t = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same counter on every XCD (s_memtime is per XCD, shader clock)
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
@@ -115,7 +114,6 @@ struct Arena {
     uint4 *ni;
     uint4 *ed;
     u16 *em;
-    uint2 *ek;
 };
 
 __device__ inline Arena arena_of(const EngineParams &P, int a, int g)
@@ -126,9 +124,24 @@ __device__ inline Arena arena_of(const EngineParams &P, int a, int g)
     A.ni = P.node_info + slot * P.node_cap;
     A.ed = P.edge + slot * P.edge_cap;
     A.em = P.edge_move + slot * P.edge_cap;
-    A.ek = P.edge_kid + slot * P.edge_cap;
     return A;
 }
+
+// The 16-byte edge record.  Everything a PUCT level needs about a child sits in it: 16 B per child instead of the 24
+// of a separate (first_edge, n_edges) array — the descents of thousands of games are in flight together and their
+// level loads share the memory system (tools/tree_stamps.py: a level costs 0.93 us at 1024 games, 1.37 at 4096).
+//   x  prior (f32 bits)                      y  total score W (f32 bits)
+//   z  visits (bits 0-15) | child node (bits 16-31, ENONE = not expanded)
+//   w  the child's first edge (bits 0-22) | its edge count (bits 23-30) | finished position (bit 31)
+// visits <= 60000 and nodes <= visits + 8 (azh_engine_create), edges per game < 2^23, moves per position <= 255.
+constexpr u32 ENONE = 0xFFFFu;
+__device__ inline u32 edge_visits(const uint4 &e) { return e.z & 0xFFFFu; }
+__device__ inline u32 edge_child(const uint4 &e) { return e.z >> 16; }
+__device__ inline uint4 fresh_edge(u32 prior_bits) { return make_uint4(prior_bits, 0u, ENONE << 16, 0u); }
+__device__ inline u32 pack_kid(u32 first, u32 n_edges, u32 finished) { return first | (n_edges << 23) | (finished << 31); }
+__device__ inline u32 kid_first(u32 w) { return w & 0x7FFFFFu; }
+__device__ inline int kid_count(u32 w) { return (int)((w >> 23) & 0xFFu); }
+__device__ inline bool kid_finished(u32 w) { return (w >> 31) != 0u; }
 
 // ONE_RANDOM_MOVE (:515-518): ply of the uniformly random move, uniform on 0..119, a pure function of
 // (seed, game uid).
@@ -208,9 +221,8 @@ __device__ inline void init_game_at(const EngineParams &P, int g, u32 uid, azh_g
     const int M = wave_movegen(b, P.blockers, s_moves, &res);
     wave_sync();
     for (int j = lane; j < M; j += WAVE) {
-        A.ed[j] = make_uint4(0u, 0u, 0u, NONE);
+        A.ed[j] = fresh_edge(0u);
         A.em[j] = s_moves[j];
-        A.ek[j] = make_uint2(0u, 0u);
     }
     if (lane == 0) {
         A.nb[0] = make_ulonglong2(pack_word0(b), b.o);
@@ -305,7 +317,8 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
         u32 node = resume ? (u32)s.leaf_node : 0u;
         depth = resume ? s.path_len : 0;
         const uint4 rinfo = A.ni[node];
-        u32 first = rinfo.x, ninfo = rinfo.y;  // edge range + result of the node being scanned
+        // edge range of the node being scanned, in the packed form the edges carry for their children
+        u32 kid = pack_kid(rinfo.x, rinfo.y & 0xFFFFu, (rinfo.y >> 16) != 0u);
         int levels_done = 0;
         for (;;) {
             if (P.select_budget != 0 && levels_done == P.select_budget) {
@@ -315,9 +328,9 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
                 break;
             }
             levels_done++;
-            const int M = (int)(ninfo & 0xFFFFu);
-            const int result = (int)(ninfo >> 16);
-            if (result != 0 || M == 0) {
+            const int M = kid_count(kid);
+            const u32 first = kid_first(kid);
+            if (kid_finished(kid) || M == 0) {
                 kind = AZH_LEAF_TERMINAL;  // select_action -> NO_MOVE (:336-340)
                 leaf_node = (int)node;
                 break;
@@ -329,18 +342,15 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
                 // Fast path (nearly every node): one edge per lane.  Same arithmetic as the general path below;
                 // the arg-max is a 32-bit max of the score bits plus a ballot for the tie rule, instead of a
                 // 64-bit (score, index) key reduction — this loop is a latency chain, instructions count.
-                uint4 e1 = make_uint4(0u, 0u, 0u, NONE);
-                uint2 k1 = make_uint2(0u, 0u);
+                uint4 e1 = fresh_edge(0u);
                 const bool live = lane < M;
-                if (live) {
+                if (live)
                     e1 = A.ed[first + lane];
-                    k1 = A.ek[first + lane];
-                }
-                const u32 ntot1 = wave_sum_u32(e1.y);
+                const u32 n = edge_visits(e1);
+                const u32 ntot1 = wave_sum_u32(n);
                 const float sq1 = sqrtf((float)(1u + ntot1));
                 const float prior = u2f(e1.x);
-                const u32 n = e1.y;
-                const float W = u2f(e1.z);
+                const float W = u2f(e1.y);
                 const float q = n ? W / (float)n : 0.0f;
                 const float u = (sq1 / (1.0f + (float)n)) * (P.c_puct * prior);
                 const float score = u + q;
@@ -355,11 +365,10 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
                 if (lane == 0)
                     path[depth] = (int)eidx;
                 depth++;
-                const u32 child = (u32)read_lane((int)e1.w, bj);
-                if (child != NONE) {
+                const u32 child = edge_child(make_uint4(0u, 0u, (u32)read_lane((int)e1.z, bj), 0u));
+                if (child != ENONE) {
                     node = child;
-                    first = (u32)read_lane((int)k1.x, bj);
-                    ninfo = (u32)read_lane((int)k1.y, bj);
+                    kid = (u32)read_lane((int)e1.w, bj);
                     continue;
                 }
                 // fall through to the expansion below with the general path's variable
@@ -367,17 +376,14 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
             } else {
             const int rounds = (M + 63) >> 6;
             uint4 ev[4];
-            uint2 kv[4];
             u32 nsum = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                ev[k] = make_uint4(0u, 0u, 0u, NONE);
-                kv[k] = make_uint2(0u, 0u);
+                ev[k] = fresh_edge(0u);
                 const int j = lane + 64 * k;
                 if (k < rounds && j < M) {
                     ev[k] = A.ed[first + j];
-                    kv[k] = A.ek[first + j];  // independent load: same round trip as the edge
-                    nsum += ev[k].y;
+                    nsum += edge_visits(ev[k]);
                 }
             }
             const u32 ntot = wave_sum_u32(nsum);
@@ -391,24 +397,22 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
             // no array is indexed by the (run-time) round of the winner (that put the arrays in scratch memory
             // and a scratch round trip into every level)
             u64 key = 0;
-            u32 mine = ev[0].w;
-            u32 mkx = kv[0].x, mky = kv[0].y;
+            u32 mine = ev[0].z, mkid = ev[0].w;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int j = lane + 64 * k;
                 if (k < rounds && j < M) {
                     const float prior = u2f(ev[k].x);
-                    const u32 n = ev[k].y;
-                    const float W = u2f(ev[k].z);
+                    const u32 n = edge_visits(ev[k]);
+                    const float W = u2f(ev[k].y);
                     const float q = n ? W / (float)n : 0.0f;
                     const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
                     const float score = u + q;
                     const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)((u32)j ^ tie_flip) : 0ull;
                     if (kj > key) {
                         key = kj;
-                        mine = ev[k].w;
-                        mkx = kv[k].x;
-                        mky = kv[k].y;
+                        mine = ev[k].z;
+                        mkid = ev[k].w;
                     }
                 }
             }
@@ -418,11 +422,10 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
             if (lane == 0)
                 path[depth] = (int)eidx;
             depth++;
-            const u32 child = (u32)read_lane((int)mine, bj & 63);
-            if (child != NONE) {
+            const u32 child = (u32)read_lane((int)mine, bj & 63) >> 16;
+            if (child != ENONE) {
                 node = child;
-                first = (u32)read_lane((int)mkx, bj & 63);
-                ninfo = (u32)read_lane((int)mky, bj & 63);
+                kid = (u32)read_lane((int)mkid, bj & 63);
                 continue;
             }
             sel_eidx = eidx;
@@ -436,7 +439,7 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
             int res2;
             const int M2 = wave_movegen(cb, P.blockers, s_moves, &res2);
             wave_sync();
-            if (s.n_nodes >= P.node_cap || (res2 == 0 && s.n_edges + M2 > P.edge_cap)) {
+            if (s.n_nodes >= P.node_cap || (res2 == 0 && (s.n_edges + M2 > P.edge_cap || M2 > 255))) {
                 over = 1;
                 kind = AZH_LEAF_NONE;
                 leaf_node = 0;
@@ -460,9 +463,8 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
                 const uint4 kinfo = A.ni[known];
                 const u32 nf = (u32)s.n_edges;
                 for (int j = lane; j < M2; j += WAVE) {
-                    A.ed[nf + j] = make_uint4(A.ed[kinfo.x + j].x, 0u, 0u, NONE);
+                    A.ed[nf + j] = fresh_edge(A.ed[kinfo.x + j].x);
                     A.em[nf + j] = s_moves[j];
-                    A.ek[nf + j] = make_uint2(0u, 0u);
                 }
                 s.n_edges += M2;
                 if (lane == 0)
@@ -473,9 +475,8 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
             } else {
                 const u32 nf = (u32)s.n_edges;
                 for (int j = lane; j < M2; j += WAVE) {
-                    A.ed[nf + j] = make_uint4(0u, 0u, 0u, NONE);
+                    A.ed[nf + j] = fresh_edge(0u);
                     A.em[nf + j] = s_moves[j];
-                    A.ek[nf + j] = make_uint2(0u, 0u);
                 }
                 s.n_edges += M2;
                 if (lane == 0)
@@ -486,8 +487,9 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
             }
             if (lane == 0) {
                 A.nb[cid] = make_ulonglong2(pack_word0(cb), cb.o);
-                reinterpret_cast<u32 *>(&A.ed[eidx])[3] = cid;
-                A.ek[eidx] = res2 != 0 ? make_uint2(0u, (u32)res2 << 16) : make_uint2((u32)(s.n_edges - M2), (u32)M2);
+                // the edge gets its child (an edge without a child has no visits: the first one creates it) and the child's range
+                reinterpret_cast<uint2 *>(&A.ed[eidx])[1] =
+                    make_uint2(cid << 16, res2 != 0 ? pack_kid(0u, 0u, 1u) : pack_kid((u32)(s.n_edges - M2), (u32)M2, 0u));
             }
             leaf_node = (int)cid;
             leaf_mover = cb.turn ? cb.o : cb.x;
@@ -503,6 +505,8 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
         st[5] = tree_stamp();
         if (st[4] == 0)
             st[4] = st[5];  // no expansion: the descent ended at a finished position, parked, or there was none
+        st[8] = st_levels;
+        st[9] = st_children;
     }
     if (lane == 0) {
         P.gs[g] = s;
@@ -688,8 +692,8 @@ __device__ inline void backup_game(const EngineParams &P, int g, azh_game_state 
             const int flips = s.path_len - i;
             const float val = flips == 1 ? fa : ((flips & 1) ? fc : fb);
             u32 *e = reinterpret_cast<u32 *>(&A.ed[path[i]]);
-            e[2] = f2u(u2f(e[2]) + val);
-            e[1] += 1u;
+            e[1] = f2u(u2f(e[1]) + val);
+            e[2] += 1u;  // visits: the low half of the word (<= 60000, never carries into the child id)
         }
         if (s.path_len > 0)
             s.root_visits += 1;
@@ -706,14 +710,14 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     u16 *s_moves = L.moves;
     u32 *s_old = L.old, *s_pref = L.pref;
     u64 *s_w = L.w;
-    u32 *spill = P.bfs_spill + (size_t)g * 4 * P.node_cap;
+    u32 *spill = P.bfs_spill + (size_t)g * 3 * P.node_cap;
     const int node_cap = P.node_cap;
     // frontier queue accessors: LDS for the first BFS_QL nodes, HBM beyond
-    auto q_put = [&](u32 i, u32 a, u32 b, u32 c, u32 d) {
+    auto q_put = [&](u32 i, u32 a, u32 b, u32 c) {
         if (i < (u32)BFS_QL) {
-            L.q[0][i] = a; L.q[1][i] = b; L.q[2][i] = c; L.q[3][i] = d;
+            L.q[0][i] = a; L.q[1][i] = b; L.q[2][i] = c;
         } else {
-            spill[i] = a; spill[node_cap + i] = b; spill[2 * node_cap + i] = c; spill[3 * node_cap + i] = d;
+            spill[i] = a; spill[node_cap + i] = b; spill[2 * node_cap + i] = c;
         }
     };
     auto q_get = [&](u32 i, int f) -> u32 { return i < (u32)BFS_QL ? L.q[f][i] : spill[(size_t)f * node_cap + i]; };
@@ -732,17 +736,18 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     const Philox4 rr = philox(P.k0, P.k1, s.uid, (u32)s.ply, STREAM_SAMPLE, 0u);
     const u32 N = (u32)s.root_visits;
     const u32 r = (u32)(((u64)rr.v[0] * (u64)N) >> 32);
-    uint4 ev[4];
-    u32 mvs[4];
+    u32 nv[4], ch[4], mvs[4];  // visits, child node, move of this lane's root edges
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = lane + 64 * k;
-        ev[k] = make_uint4(0u, 0u, 0u, NONE);
+        uint4 ev = fresh_edge(0u);
         mvs[k] = 0;
         if (j < M) {
-            ev[k] = A.ed[first + j];
+            ev = A.ed[first + j];
             mvs[k] = A.em[first + j];
         }
+        nv[k] = edge_visits(ev);
+        ch[k] = edge_child(ev);
     }
     int chosen = -1;
     if (P.flags & AZH_FLAG_SAMPLE_POW5) {
@@ -751,13 +756,13 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
         u64 mk = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            mk = (u64)ev[k].y > mk ? (u64)ev[k].y : mk;
+            mk = (u64)nv[k] > mk ? (u64)nv[k] : mk;
         const u64 maxn = wave_max_u64(mk);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = lane + 64 * k;
             if (j < M) {
-                const u64 n = ev[k].y;
+                const u64 n = nv[k];
                 s_w[j] = (2 * n >= maxn) ? n * n * n * n * n : 0ull;
             }
         }
@@ -785,7 +790,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = lane + 64 * k;
-            const int incl = wave_incl_scan((int)ev[k].y);
+            const int incl = wave_incl_scan((int)nv[k]);
             const u32 cum = run + (u32)incl;
             const u64 mask = __ballot(j < M && cum > r);
             if (chosen < 0 && mask)
@@ -807,7 +812,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
             for (int k = 0; k < 4; k++) {
                 const int j = lane + 64 * k;
                 if (j < M) {
-                    const u64 kk = ((u64)ev[k].y << 32) | (u64)(0xFFFFFFFFu - (u32)j);
+                    const u64 kk = ((u64)nv[k] << 32) | (u64)(0xFFFFFFFFu - (u32)j);
                     key = kk > key ? kk : key;
                 }
             }
@@ -823,17 +828,17 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int j = lane + 64 * k;
-        const bool has = j < M && ev[k].w != NONE;
+        const bool has = j < M && ch[k] != ENONE;
         const u64 mask = __ballot(has);
         if (has)
-            rec[REC_HDR_WORDS + nd + __popcll(mask & lt)] = mvs[k] | ((ev[k].y & 0xFFFFu) << 16);
+            rec[REC_HDR_WORDS + nd + __popcll(mask & lt)] = mvs[k] | (nv[k] << 16);
         nd += __popcll(mask);
     }
     const int ck = chosen >> 6, cl = chosen & 63;
     const u32 my_mv = ck == 0 ? mvs[0] : (ck == 1 ? mvs[1] : (ck == 2 ? mvs[2] : mvs[3]));
-    const u32 my_ch = ck == 0 ? ev[0].w : (ck == 1 ? ev[1].w : (ck == 2 ? ev[2].w : ev[3].w));
+    const u32 my_ch = ck == 0 ? ch[0] : (ck == 1 ? ch[1] : (ck == 2 ? ch[2] : ch[3]));
     const u32 mv = (u32)read_lane((int)my_mv, cl);
-    const u32 c = (P.flags & AZH_FLAG_NO_REUSE) ? NONE : (u32)read_lane((int)my_ch, cl);  // arena engines rebuild the tree every ply
+    const u32 c = (P.flags & AZH_FLAG_NO_REUSE) ? ENONE : (u32)read_lane((int)my_ch, cl);  // arena engines rebuild the tree every ply
     const ulonglong2 rootw = A.nb[0];
     if (lane == 0) {
         const u64 bx = rootw.x & ~TURN_BIT;
@@ -851,16 +856,15 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     // into the other arena (children keep their edge order).
     int result;
     u64 st_nodes = 0, st_edges = 0, st_spill = 0;
-    if (c == NONE) {
+    if (c == ENONE) {
         // miss: fresh tree from the position after the move (:479-483)
         const Board nbrd = make_move(unpack_board(rootw.x, rootw.y), (int)(mv & 0xFF), (int)(mv >> 8));
         const int Mn = wave_movegen(nbrd, P.blockers, s_moves, &result);
         wave_sync();
         const int Mw = result != 0 ? 0 : Mn;
         for (int j = lane; j < Mw; j += WAVE) {
-            B.ed[j] = make_uint4(0u, 0u, 0u, NONE);
+            B.ed[j] = fresh_edge(0u);
             B.em[j] = s_moves[j];
-            B.ek[j] = make_uint2(0u, 0u);
         }
         if (lane == 0) {
             float tv = result == 1 ? 1.0f : -1.0f;
@@ -879,21 +883,21 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
         // (parent order, edge order) and a node's edges land at the running edge count,
         // exactly as the node-at-a-time loop of the oracle does, so the compacted arena is
         // bit-identical.  The frontier (old node id, old edge range, parent edge) is queued in
-        // LDS when a child is discovered — its edge range comes from edge_kid, read in the same
-        // round trip as the edge — so one pass costs ONE dependent memory round trip.
+        // LDS when a child is discovered — its edge range is part of the edge that leads to it —
+        // so one pass costs ONE dependent memory round trip.
         u32 t = 1, eb = 0, rv = 0, qs = 0;
         if (lane == 0)
-            q_put(0u, c, cinfo.x, cinfo.y, 0u);
+            q_put(0u, c, pack_kid(cinfo.x, cinfo.y & 0xFFFFu, (cinfo.y >> 16) != 0u), 0u);
         wave_sync();
         while (qs < t) {
             const u32 nchunk = min(t - qs, (u32)WAVE);
-            u32 of = 0, Mq = 0, qy = 0, old = 0, pe = 0;
+            u32 of = 0, Mq = 0, kw = 0, old = 0, pe = 0;
             if ((u32)lane < nchunk) {
                 old = q_get(qs + lane, 0);
-                of = q_get(qs + lane, 1);
-                qy = q_get(qs + lane, 2);
-                pe = q_get(qs + lane, 3);
-                Mq = qy & 0xFFFFu;
+                kw = q_get(qs + lane, 1);
+                pe = q_get(qs + lane, 2);
+                of = kid_first(kw);
+                Mq = (u32)kid_count(kw);
             }
             const u32 incl = (u32)wave_incl_scan((int)Mq);
             const u32 Ef = (u32)bcast_last((int)incl);
@@ -903,9 +907,10 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
                 s_pref[lane] = incl - Mq;
                 // node copy: not on the dependent chain (nothing below waits for these loads)
                 B.nb[qs + lane] = A.nb[old];
-                B.ni[qs + lane] = make_uint4(nf, qy, 0u, A.ni[old].w);
-                if (qs + lane > 0)
-                    B.ek[pe] = make_uint2(nf, qy);
+                const uint4 oinfo = A.ni[old];
+                B.ni[qs + lane] = make_uint4(nf, oinfo.y, 0u, oinfo.w);
+                if (qs + lane > 0)  // the edge that leads here was copied in an earlier pass: now it learns the new range
+                    reinterpret_cast<u32 *>(&B.ed[pe])[3] = pack_kid(nf, Mq, kid_finished(kw));
             }
             if (lane == 0)
                 s_pref[nchunk] = Ef;
@@ -913,8 +918,7 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
             for (u32 e0 = 0; e0 < Ef; e0 += WAVE) {
                 const u32 e = e0 + (u32)lane;
                 const bool valid = e < Ef;
-                uint4 ed = make_uint4(0u, 0u, 0u, NONE);
-                uint2 kd = make_uint2(0u, 0u);
+                uint4 ed = fresh_edge(0u);
                 u16 m = 0;
                 if (valid) {
                     u32 lo = 0, hi = nchunk;  // largest i with s_pref[i] <= e
@@ -925,24 +929,21 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
                     }
                     const u32 src = s_old[lo] + (e - s_pref[lo]);
                     ed = A.ed[src];
-                    kd = A.ek[src];
                     m = A.em[src];
                     if (qs == 0 && lo == 0)
-                        rv += ed.y;
+                        rv += edge_visits(ed);
                 }
-                const bool has = valid && ed.w != NONE;
+                const bool has = valid && edge_child(ed) != ENONE;
                 const u64 mask = __ballot(has);
                 const u32 dst = eb + e;
                 if (has) {
                     const u32 nc = t + (u32)__popcll(mask & lt);
-                    q_put(nc, ed.w, kd.x, kd.y, dst);
-                    ed.w = nc;
+                    q_put(nc, edge_child(ed), ed.w, dst);
+                    ed.z = (ed.z & 0xFFFFu) | (nc << 16);  // (ed.w still names the OLD range: rewritten when the child is copied)
                 }
                 if (valid) {
                     B.ed[dst] = ed;
                     B.em[dst] = m;
-                    if (!has)
-                        B.ek[dst] = make_uint2(0u, 0u);
                 }
                 t += (u32)__popcll(mask);
             }
@@ -1312,6 +1313,9 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
         cfg->edges_per_node < 8)
         return azh_fail(-2, "azh_engine_create: bad config (games %d visits %d max_plies %d edges_per_node %d)",
                         cfg->games, cfg->visits, cfg->max_plies, cfg->edges_per_node);
+    if ((long long)(cfg->visits + 8) * cfg->edges_per_node >= (1 << 23))
+        return azh_fail(-2, "azh_engine_create: (visits + 8) * edges_per_node = %lld edges per game do not fit the 23-bit edge "
+                            "index of the tree's edge records", (long long)(cfg->visits + 8) * cfg->edges_per_node);
     if (azh_require_device())
         return -3;
     azh_engine *e = new azh_engine();
@@ -1355,7 +1359,6 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.node_info, 2 * G * P.node_cap);
     rc |= dev_alloc(e, &P.edge, 2 * G * P.edge_cap);
     rc |= dev_alloc(e, &P.edge_move, 2 * G * P.edge_cap);
-    rc |= dev_alloc(e, &P.edge_kid, 2 * G * P.edge_cap);
     rc |= dev_alloc(e, &P.leaf_board, G);
     rc |= dev_alloc(e, &P.need_eval, G);
     rc |= dev_alloc(e, &P.leaf_list, G);
@@ -1369,7 +1372,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.ring, P.ring_cap_words);
     rc |= dev_alloc(e, &P.ring_head, 1);
     rc |= dev_alloc(e, &P.stats, G * NSTAT);
-    rc |= dev_alloc(e, &P.bfs_spill, G * 4 * P.node_cap);
+    rc |= dev_alloc(e, &P.bfs_spill, G * 3 * P.node_cap);
     rc |= dev_alloc(e, &e->d_stat_out, NSTAT);
     if (rc) {
         azh_engine_destroy(e);
@@ -1641,8 +1644,9 @@ extern "C" int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_
 }
 
 // Diagnostic: two search iterations of the device loop, the tree launch between the two towers being the stamped
-// instantiation of k_tree; out [games][8] u64 = s_memtime readings (100 MHz) per game: wave start, state loaded, backup
-// done, mark done, descent done, expansion done, state stored, workgroup done.
+// instantiation of k_tree; out [games][10] u64 = s_memrealtime readings (100 MHz) per game: wave start, state loaded,
+// backup done, mark done, descent done, expansion done, state stored, workgroup done; then the levels descended and the
+// children scanned by that descent.
 extern "C" int azh_engine_tree_stamps(azh_engine *e, azh_net *net, int dtype, uint64_t *out)
 {
     if (!e || !net || !out)
@@ -1760,7 +1764,16 @@ extern "C" int azh_engine_tree(azh_engine *e, int game, uint64_t *boards, uint32
     const size_t slot = (size_t)s.arena * e->P.G + game;
     if (boards) AZH_HIP(hipMemcpy(boards, e->P.node_board + slot * e->P.node_cap, (size_t)s.n_nodes * 16, hipMemcpyDeviceToHost));
     if (info) AZH_HIP(hipMemcpy(info, e->P.node_info + slot * e->P.node_cap, (size_t)s.n_nodes * 16, hipMemcpyDeviceToHost));
-    if (edges) AZH_HIP(hipMemcpy(edges, e->P.edge + slot * e->P.edge_cap, (size_t)s.n_edges * 16, hipMemcpyDeviceToHost));
+    if (edges) {
+        AZH_HIP(hipMemcpy(edges, e->P.edge + slot * e->P.edge_cap, (size_t)s.n_edges * 16, hipMemcpyDeviceToHost));
+        for (int j = 0; j < s.n_edges; j++) {  // device record (prior, W, visits | child << 16, child's range) -> documented row
+            uint32_t *r = edges + 4 * (size_t)j;
+            const uint32_t w = r[1], z = r[2];
+            r[1] = z & 0xFFFFu;
+            r[2] = w;
+            r[3] = (z >> 16) == 0xFFFFu ? 0xFFFFFFFFu : (z >> 16);
+        }
+    }
     if (moves) AZH_HIP(hipMemcpy(moves, e->P.edge_move + slot * e->P.edge_cap, (size_t)s.n_edges * 2, hipMemcpyDeviceToHost));
     return 0;
 }

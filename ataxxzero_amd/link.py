@@ -380,8 +380,9 @@ class Engine:
         return {n: int(out[i]) for i, n in enumerate(STAT_NAMES)}
 
     def tree_stamps(self, net, dtype=DTYPE_BF16):
-        """(G, 8) s_memtime readings (100 MHz) of one stamped tree launch of the device loop (two iterations are run)."""
-        out = np.zeros((self.G, 8), dtype=np.uint64)
+        """(G, 10): 8 s_memrealtime readings (100 MHz) of one stamped tree launch of the device loop (two iterations are
+        run), then the levels descended and the children scanned."""
+        out = np.zeros((self.G, 10), dtype=np.uint64)
         check(load().azh_engine_tree_stamps(self.h, net.h, dtype, _ptr(out)))
         return out
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the time of the fused tree launch (k_tree) goes, from in-kernel s_memtime stamps (diagnostic instantiation).
+"""Where the time of the fused tree launch (k_tree) goes, from in-kernel s_memrealtime stamps (diagnostic instantiation).
 
 The engine is put in bench.py's steady state (positions of profiles/round2_steady_state_positions.npz, trees grown),
 then `--samples` stamped launches are taken, a few ordinary iterations apart.  Per game wave the stamps are: wave start,
@@ -48,7 +48,7 @@ def main():
         sp.drain()
         done += 250
     e = sp.engine
-    rows, spans, skews, wg_waits, levels = [], [], [], [], []
+    rows, spans, skews, wg_waits, levels, per_level = [], [], [], [], [], []
     for _ in range(args.samples):
         st0 = e.stats()
         t = e.tree_stamps(sp.net, link.DTYPES[args.dtype]).astype(np.int64)
@@ -59,6 +59,9 @@ def main():
         spans.append((t[:, 7].max() - t[:, 0].min()) / 100.0)
         skews.append((t[:, 0] - t[:, 0].min()) / 100.0)
         wg_waits.append((t[:, 7] - t[:, 6]) / 100.0)
+        deep = t[:, 8] >= 8
+        per_level.append(np.stack([(t[deep, 4] - t[deep, 3]) / 100.0 / t[deep, 8], t[deep, 8], t[deep, 9] / t[deep, 8],
+                                   (t[deep, 3] - t[:, 0].min()) / 100.0], axis=1))
         # two iterations ran; the stamped one is the first's tree phase: levels per step over both, as context
         levels.append((st1["levels"] - st0["levels"]) / max(1, st1["steps"] - st0["steps"]))
     d = np.concatenate(rows)
@@ -72,6 +75,13 @@ def main():
     total = d.sum(axis=1)
     print("%-42s %8.2f %8.2f %8.2f %8.2f" % ("one game, start to state stored", total.mean(), np.median(total),
                                               np.percentile(total, 90), total.max()))
+    pl = np.concatenate(per_level)
+    print("descents of >= 8 levels: %.3f us per level on average (p50 %.3f, p90 %.3f); %.1f levels, %.1f children per level" % (
+        pl[:, 0].mean(), np.median(pl[:, 0]), np.percentile(pl[:, 0], 90), pl[:, 1].mean(), pl[:, 2].mean()))
+    for lo, hi in ((8, 16), (16, 32), (32, 47), (47, 1000)):
+        m = (pl[:, 1] >= lo) & (pl[:, 1] < hi)
+        if m.any():
+            print("   %3d-%-4d levels: %6d descents, %.3f us per level" % (lo, hi, m.sum(), pl[m, 0].mean()))
     sk = np.concatenate(skews)
     print("%-42s %8.2f %8.2f %8.2f %8.2f" % ("wave start after the launch's first wave", sk.mean(), np.median(sk),
                                               np.percentile(sk, 90), sk.max()))
