@@ -55,6 +55,8 @@ struct EngineParams {
     int start_turn;
     u32 flags;
     int select_budget;  // tree levels per select launch and game (0 = unlimited), azh_config.select_budget
+    u32 uid_limit;       // azh_engine_set_game_limit: games with uid >= this are not started (0 = no limit); a slot whose
+                         // next game would be one of them goes idle (phase 3: no leaf, no move, nothing to back up)
     u32 *tt;             // AZH_FLAG_EVAL_CACHE: [2][G][tt_size] open-addressed table of evaluated nodes, keyed by the board
     int tt_size;         // power of two >= 4 * node_cap
     int *no_emit;        // [G] start ply + 1 when the slot's current game was started from a loaded position
@@ -245,9 +247,19 @@ __device__ inline void init_game_at(const EngineParams &P, int g, u32 uid, azh_g
     s.uid = uid;
 }
 
-// Fresh game at the configured start position.
+// Fresh game at the configured start position — or, past the game limit, no game: the slot goes idle.
 __device__ inline void init_game(const EngineParams &P, int g, u32 uid, azh_game_state &s, u16 *s_moves)
 {
+    if (P.uid_limit != 0u && uid >= P.uid_limit) {
+        s.phase = 3;
+        s.uid = uid;
+        s.leaf_kind = AZH_LEAF_NONE;
+        s.path_len = 0;
+        s.root_visits = 0;
+        if (lane_id() == 0)
+            P.force[g] = 0;
+        return;
+    }
     Board b;
     b.x = P.start_x;
     b.o = P.start_o;
@@ -265,6 +277,14 @@ __global__ __launch_bounds__(WAVE) void k_init_positions(EngineParams P, const u
     init_game_at(P, g, (u32)g, s, s_moves, unpack_board(w.x, w.y), plies[g], 1);
     if (threadIdx.x == 0)
         P.gs[g] = s;
+}
+
+// azh_engine_set_game_limit before the first iteration: the slots whose first game is already past the limit go idle
+__global__ void k_idle_slots(EngineParams P)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < P.G && P.gs[g].uid >= P.uid_limit)
+        P.gs[g].phase = 3;
 }
 
 __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
@@ -293,8 +313,9 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
     u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0, st_cached = 0, st_parked = 0;
     u64 leaf_mover = 0, leaf_opp = 0;
 
-    if (s.phase == 2) {
-        // the move of this game is due: its re-root runs after this select (k_advance_list), no leaf now
+    if (s.phase >= 2) {
+        // 2: the move of this game is due: its re-root runs after this select (k_advance_list), no leaf now
+        // 3: the slot is idle (azh_engine_set_game_limit: every game it was to play has been played)
         kind = AZH_LEAF_NONE;
     } else if (s.phase == 0 && (P.flags & AZH_FLAG_TWO_NETS) && (A.ni[0].y & 0xFFFFu) == 1u) {
         // arena: a single legal move is played without search (uai_ringmaster.py:114-116)
@@ -1676,6 +1697,22 @@ extern "C" int azh_engine_set_visits(azh_engine *e, int visits)
         return azh_fail(-1, "azh_engine_set_visits: need 1 <= visits <= %d", e ? e->cfg.visits : 0);
     AZH_HIP(hipStreamSynchronize(e->stream));
     e->P.visits = visits;
+    return 0;
+}
+
+// At most `games` games are played: uids 0 .. games - 1 (slot g plays uids g, g + G, ...).  A slot whose next game
+// would be past the limit goes idle, so the batch thins out as the last games end and no search is spent on games
+// nobody asked for — what a generator given a target count (accelerated_generate_games.py --game-count) wants in
+// uid order, where line N only appears once the slowest of the first N games has ended.  Call before the first iteration.
+extern "C" int azh_engine_set_game_limit(azh_engine *e, int64_t games)
+{
+    if (!e || games < 1 || games > 0xFFFFFFFFll)
+        return azh_fail(-1, "azh_engine_set_game_limit: bad argument");
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    e->P.uid_limit = (u32)games;
+    hipLaunchKernelGGL(k_idle_slots, dim3((e->P.G + 255) / 256), dim3(256), 0, e->stream, e->P);
+    AZH_HIP(hipGetLastError());
+    AZH_HIP(hipStreamSynchronize(e->stream));
     return 0;
 }
 

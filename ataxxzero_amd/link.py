@@ -102,6 +102,7 @@ SIGNATURES = {
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
     "azh_engine_set_emit_order": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_set_positions": (ctypes.c_int, [_vp, _vp, _vp]),
+    "azh_engine_set_game_limit": (ctypes.c_int, [_vp, ctypes.c_int64]),
     # the reference's ABI, link.py:8-32
     "launch_threads": (None, [ctypes.c_char_p, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     "get_workload": (ctypes.c_int, []),
@@ -359,6 +360,10 @@ class Engine:
     def set_emit_order(self, by_uid):
         """True: finished games are handed out in uid order (unbiased prefixes); False: as they finish."""
         check(load().azh_engine_set_emit_order(self.h, 1 if by_uid else 0))
+
+    def set_game_limit(self, games):
+        """Play uids 0 .. games - 1 only; slots past the limit go idle (call before the first iteration)."""
+        check(load().azh_engine_set_game_limit(self.h, int(games)))
 
     def game_state(self, g):
         s = GameState()

@@ -121,6 +121,12 @@ class SelfPlay:
         for e in self.engines:
             e.set_emit_order(by_uid)
 
+    def set_game_limit(self, games):
+        """`games` games in all, then the slots go idle (one engine only: uids are per engine)."""
+        if len(self.engines) != 1:
+            raise ValueError("a game limit needs --streams 1")
+        self.engine.set_game_limit(games)
+
     def drain(self):
         lines = []
         for e in self.engines:

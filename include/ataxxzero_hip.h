@@ -257,6 +257,12 @@ int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, 
  * ones; with thousands of games in flight that bias is no longer slight, and uid order removes it (the first N
  * lines are the first N games started).  Call before the first drain. */
 int azh_engine_set_emit_order(azh_engine *e, int by_uid);
+/* Play at most `games` games (uids 0 .. games - 1) and then stop searching: a slot whose next game would be past the
+ * limit goes idle, the batch thins out as the last games end.  For a generator that was given a target count: in uid
+ * order line N appears once the slowest of the first N games has ended, and without a limit every other slot meanwhile
+ * plays games nobody will read.  Call before the first iteration.  (The reference's client has no such notion: it is
+ * stopped from outside, looper.py:51-64.) */
+int azh_engine_set_game_limit(azh_engine *e, int64_t games);
 
 /* ------------------------------------------------------------------ reference ABI
  * The four symbols link.py:6-32 binds (cpp/self_play_client.cpp:683-749), with

@@ -120,6 +120,42 @@ def test_device_resident_selfplay_with_builtin_net(dtype, visits):
         assert all(min(d.values()) > 0 for d in entry["dists"])
 
 
+def test_game_limit_plays_exactly_the_games_below_it_and_then_idles():
+    """azh_engine_set_game_limit: uids 0 .. N - 1 are played (slot g: g, g + G, ...), a slot whose next game would be past
+    the limit goes idle, and the games are the ones the unlimited engine plays under those uids."""
+    conv, bn = model.random_init(1, 128, seed=9)
+    net = link.Net(conv, bn)
+    G, N = 48, 100
+    ocfg = orc.make_config(G, 6, seed=3, max_plies=400)
+    mk = lambda: link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+    limited, free = mk(), mk()
+    limited.set_emit_order(True)
+    free.set_emit_order(True)
+    limited.set_game_limit(N)
+    lines = []
+    for _ in range(400):
+        limited.run(net, 100, link.DTYPE_F32)
+        lines += limited.drain_json()
+        st = limited.stats()
+        if st["games"] + st["dropped"] >= N:
+            break
+    assert st["games"] + st["dropped"] == N and len(lines) == st["games"]
+    assert all(limited.game_state(g).phase == 3 and limited.game_state(g).uid >= N for g in range(G))
+    limited.run(net, 50, link.DTYPE_F32)
+    limited.sync()
+    assert limited.stats() == st and limited.drain_json() == []     # idle: no search, no games
+    # the unlimited engine, same seed: its first games in uid order are the same games (f32 tower: position-independent)
+    want = []
+    for _ in range(400):
+        free.run(net, 100, link.DTYPE_F32)
+        want += free.drain_json()
+        if len(want) >= len(lines):
+            break
+    assert want[:len(lines)] == lines
+    with pytest.raises(link.AzhError):
+        limited.set_game_limit(0)
+
+
 def test_reroot_queue_spill_path_matches_oracle():
     # visits > 512: kept subtrees grow past the LDS part of the re-root frontier queue, so the
     # HBM spill path of advance_game is exercised; still bit-exact against the oracle

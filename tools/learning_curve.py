@@ -110,13 +110,13 @@ def train(args, n, out):
             "val_loss_last": [float(x) for x in losses[-1][1:]] if losses else None}
 
 
-def arena(args, k, out):
-    """model-00k against model-001, every pairing both ways, through the ringmaster drop-in."""
+def arena(args, k, out, other=1):
+    """model-00k against model-00`other`, every pairing both ways, through the ringmaster drop-in."""
     eng = "python uai_interface.py --network-path %s --visits %d"
     cmd = [sys.executable, os.path.join(ROOT, "uai_ringmaster.py"),
            "--engine", eng % (model_path(args.prefix, k), args.arena_visits),
-           "--engine", eng % (model_path(args.prefix, 1), args.arena_visits),
-           "--game-count", str(args.arena_games), "--seed", str(args.seed + k)]
+           "--engine", eng % (model_path(args.prefix, other), args.arena_visits),
+           "--game-count", str(args.arena_games), "--seed", str(args.seed + 31 * k + other)]
     t0 = time.time()
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
     if res.returncode != 0:
@@ -127,7 +127,36 @@ def arena(args, k, out):
     return {"new": a, "first": b, "annulled": ann, "score": a / (a + b), "seconds": round(time.time() - t0, 1)}
 
 
+def value_check(model_file, games_file, samples=4096, seed=7):
+    """Does the net's value head point the right way, and does its policy agree with the search it was trained on?  On
+    positions of `games_file` drawn through the training pipeline's own encoders (training.make_minibatch: side to move from
+    ply parity, value target +1 when the mover went on to win): correlation of the net's value with that target, the share
+    of positions where the value has the target's sign, and the share where the policy's best move is the search's most
+    visited move.  Evaluated by the HIP tower (f32) — the net exactly as the generator and the arena run it."""
+    import random
+    import numpy as np
+    from ataxxzero_amd import link, model, training
+    link.require_gpu()
+    random.seed(seed)
+    entries = training.load_entries([games_file])
+    feats, pols, vals = training.make_minibatch(entries, samples)
+    # feature rows [x][y][c] -> leaf boards (mover, opponent): bit x + 7 * (6 - y) (cpp/self_play_client.cpp:181)
+    sq = np.array([[x + 7 * (6 - y) for y in range(7)] for x in range(7)], dtype=np.uint64)
+    mover = (feats[..., 1].astype(np.uint64) << sq).sum(axis=(1, 2), dtype=np.uint64)
+    opp = (feats[..., 2].astype(np.uint64) << sq).sum(axis=(1, 2), dtype=np.uint64)
+    net = link.Net(*model.load_model(model_file))
+    logits, values = net.forward(np.stack([mover, opp], axis=1), 0, link.DTYPE_F32)
+    v, t = values.reshape(-1).astype(np.float64), vals.reshape(-1).astype(np.float64)
+    legal = pols.reshape(samples, -1) > 0           # the search's visited moves (all legal moves it expanded)
+    masked = np.where(legal, logits.reshape(samples, -1), -np.inf)
+    print(json.dumps({"positions": samples, "value_target_correlation": float(np.corrcoef(v, t)[0, 1]),
+                      "value_sign_agreement": float(np.mean(np.sign(v) == t)), "mean_abs_value": float(np.abs(v).mean()),
+                      "policy_top1_is_most_visited": float(np.mean(masked.argmax(axis=1) == pols.reshape(samples, -1).argmax(axis=1)))}))
+
+
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--value-check":
+        return value_check(sys.argv[2], sys.argv[3])
     ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
     ap.add_argument("--prefix", required=True, help="run directory (models/ and games/ are created in it)")
     ap.add_argument("--out", required=True, help="summary text file (appended to as the run proceeds)")
@@ -187,6 +216,22 @@ def main():
         r = arena(args, k, out)
         log(out, "model-%03i vs model-001: %.1f - %.1f (annulled %d) = %.1f %%   [%.0f s]" % (
             k, r["new"], r["first"], r["annulled"], 100.0 * r["score"], r["seconds"]))
+    log(out, "")
+    log(out, "arena: every generation against its parent (the net it was trained from), same match size")
+    for k in range(3, args.iterations + 2):
+        r = arena(args, k, out, other=k - 1)
+        log(out, "model-%03i vs model-%03i: %.1f - %.1f (annulled %d) = %.1f %%   [%.0f s]" % (
+            k, k - 1, r["new"], r["first"], r["annulled"], 100.0 * r["score"], r["seconds"]))
+    log(out, "")
+    log(out, "value head and policy of model-00k on the games model-00k itself went on to play (positions it was NOT trained on), "
+             "through training.make_minibatch's encoders and the HIP tower (f32):")
+    for k in range(1, args.iterations + 1):
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--value-check", model_path(args.prefix, k),
+                              games_path(args.prefix, k)], cwd=ROOT, capture_output=True, text=True)
+        if res.returncode != 0:
+            log(out, "value check %d failed:\n%s" % (k, res.stderr[-2000:]))
+            raise SystemExit(2)
+        log(out, "model-%03i on model-%03i-0.json: %s" % (k, k, res.stdout.strip().splitlines()[-1]))
 
 
 if __name__ == "__main__":
