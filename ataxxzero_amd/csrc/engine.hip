@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <map>
 
+#include <hip/hip_ext.h>
+
 #include "azh_device.h"
 #include "azh_host.h"
 
@@ -66,6 +68,7 @@ struct EngineParams {
     int *force;
     int *adv_list;   // games whose move is due (phase 2), appended by mark_game, consumed by k_advance_list
     int *adv_count;
+    int *adv_done;   // tickets of k_advance_list's workgroups: the last one to finish empties the queue
     int *path;
     ulonglong2 *node_board;
     uint4 *node_info;
@@ -1137,6 +1140,14 @@ __global__ __launch_bounds__(WAVE) void k_advance_list(EngineParams P)
         advance_game(P, P.adv_list[i], L);
         wave_sync();
     }
+    // the workgroup that finishes last empties the queue (every workgroup has read the count by then): no memset
+    // command behind the kernel, and the kernel's own completion is the event the next tree launch waits for
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(P.adv_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        __hip_atomic_store(P.adv_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.adv_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // The dense, game-ordered leaf list(s) of k_compact, written inside the tree launch by the workgroup that finishes
@@ -1375,6 +1386,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
         rc |= dev_alloc(e, &P.tt, 2 * G * (size_t)P.tt_size);
     rc |= dev_alloc(e, &P.adv_list, G);
     rc |= dev_alloc(e, &P.adv_count, 1);
+    rc |= dev_alloc(e, &P.adv_done, 1);
     rc |= dev_alloc(e, &P.path, G * P.path_cap);
     rc |= dev_alloc(e, &P.node_board, 2 * G * P.node_cap);
     rc |= dev_alloc(e, &P.node_info, 2 * G * P.node_cap);
@@ -1456,12 +1468,12 @@ static int enqueue_compact(azh_engine *e);
 
 constexpr int ADV_GRID = 64;  // one wave each; a search iteration queues G * (1 / visits + ...) re-roots: about 11 at 4096 games
 
-// the queued re-roots, on `stream` (always after a select has passed over the queued games)
-static int enqueue_advance(azh_engine *e, hipStream_t stream)
+// the queued re-roots, on `stream` (always after a select has passed over the queued games); `done`, if given, is
+// signalled by the kernel's own completion (no separate event packet in the queue)
+static int enqueue_advance(azh_engine *e, hipStream_t stream, hipEvent_t done = nullptr)
 {
-    hipLaunchKernelGGL(k_advance_list, dim3(ADV_GRID), dim3(WAVE), 0, stream, e->P);
+    hipExtLaunchKernelGGL(k_advance_list, dim3(ADV_GRID), dim3(WAVE), 0, stream, nullptr, done, 0, e->P);
     AZH_HIP(hipGetLastError());
-    AZH_HIP(hipMemsetAsync(e->P.adv_count, 0, sizeof(int), stream));
     return 0;
 }
 
@@ -1592,14 +1604,14 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         return 0;
     const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
     const dim3 tree_grid((e->P.G + TREE_WAVES - 1) / TREE_WAVES);
-    hipLaunchKernelGGL(k_tree<false>, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, 2, two);  // select + leaf list
+    hipExtLaunchKernelGGL(k_tree<false>, tree_grid, dim3(TREE_THREADS), 0, e->stream, nullptr, e->ev_sel, 0, e->P, 2,
+                          two);  // select + leaf list
     // queued re-roots run on the side stream, under the tower that follows; the next tree launch waits for them
+    // (ev_sel is signalled by the tree launch itself, ev_adv by the re-root launch: hipExtLaunchKernelGGL's stop event —
+    // the two event-record packets that used to sit at the kernel boundaries of the main stream are gone)
     auto side_advance = [&]() -> int {
-        AZH_HIP(hipEventRecord(e->ev_sel, e->stream));
         AZH_HIP(hipStreamWaitEvent(e->stream2, e->ev_sel, 0));
-        if (enqueue_advance(e, e->stream2)) return -1;
-        AZH_HIP(hipEventRecord(e->ev_adv, e->stream2));
-        return 0;
+        return enqueue_advance(e, e->stream2, e->ev_adv);
     };
     if (side_advance()) return -1;
     for (int it = 0; it < iterations; it++) {
@@ -1624,10 +1636,11 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         const int last = it + 1 == iterations;
         AZH_HIP(hipStreamWaitEvent(e->stream, e->ev_adv, 0));
         if (e->stamp_next && !last) {
-            hipLaunchKernelGGL(k_tree<true>, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, 3, two);
+            hipExtLaunchKernelGGL(k_tree<true>, tree_grid, dim3(TREE_THREADS), 0, e->stream, nullptr, e->ev_sel, 0, e->P, 3, two);
             e->stamp_next = false;
         } else {
-            hipLaunchKernelGGL(k_tree<false>, tree_grid, dim3(TREE_THREADS), 0, e->stream, e->P, last ? 1 : 3, two);
+            hipExtLaunchKernelGGL(k_tree<false>, tree_grid, dim3(TREE_THREADS), 0, e->stream, nullptr,
+                                  last ? nullptr : e->ev_sel, 0, e->P, last ? 1 : 3, two);
         }
         AZH_HIP(hipGetLastError());
         if (!last && side_advance()) return -1;
