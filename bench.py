@@ -38,7 +38,7 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # MI355X_MICR
 HBM_PEAK_GBS = 8000.0
 ITERS_PER_STEP = 250
 TIMING_STRIDE = 8        # every 8th iteration is event-timed (an event is a barrier packet in the queue)
-PMC_SUMMARY = os.path.join("profiles", "round2_bench_pmc_k_tower.txt")
+PMC_SUMMARY = os.path.join("profiles", "round3_bench_pmc_k_tower.txt")
 
 
 def tree_bytes(d, logit_bytes=4):
@@ -53,7 +53,7 @@ def measured_traffic():
     MI355X_MICROARCH.md §HBM prescribes for gfx950, + WRITE_SIZE), as summarised by tools/prof_bench.sh into
     profiles/.  PMC counters cannot be read from inside the process, so this is the committed measurement, or null."""
     import re
-    for rel in (PMC_SUMMARY, os.path.join("profiles", "round1_bench_pmc_k_tower.txt")):
+    for rel in (PMC_SUMMARY, os.path.join("profiles", "round2_bench_pmc_k_tower.txt")):
         try:
             m = re.search(r"x2 corrected: ([0-9.e+]+) MB\), WRITE_SIZE [0-9.e+]+ KiB \(([0-9.e+]+) MB\)",
                           open(os.path.join(ROOT, rel)).read())

@@ -21,15 +21,17 @@ import csv, glob, os, re, sys
 f = max(glob.glob(os.path.join(sys.argv[1], "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
 m = re.search(r"--steps (\d+)", sys.argv[2])
 n = (int(m.group(1)) if m else 40) * 250
-for name in ("k_tower", "k_tree", "k_compact"):
+for name in ("k_tower", "k_tree", "k_advance_list"):
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if name in r["Kernel_Name"]]
     d = d[-n:]
+    if not d:
+        continue
     print("rocprofv3 kernel trace, last %d launches (the timed region): %-10s mean %.1f us  p50 %.1f us" % (
         len(d), name, sum(d) / len(d) / 1e3, sorted(d)[len(d) // 2] / 1e3))
 PY
 cat $OUT/timed_region.txt > $OUT/summary_k_tower.txt
 python3 $R/tools/prof_summary.py $OUT k_tower >> $OUT/summary_k_tower.txt 2>&1
-for k in k_tree k_select k_compact; do python3 $R/tools/prof_summary.py $OUT $k > $OUT/summary_$k.txt 2>&1; done
+for k in k_tree k_advance_list; do python3 $R/tools/prof_summary.py $OUT $k > $OUT/summary_$k.txt 2>&1; done
 find $OUT -name "*_counter_collection.csv" -delete
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete
 ls -la $OUT
