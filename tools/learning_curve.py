@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--poll-seconds", type=float, default=10.0)             # looper.py:54
+    ap.add_argument("--precision-positions", type=int, default=0,
+                    help="> 0: finish with tools/precision_in_the_loop.py on the last net (bf16 / f16 search against the f32 "
+                         "search on that many positions)")
     ap.add_argument("--generator-flags", type=str, default="--buffer-size 1024",
                     help="extension flags appended to the generator command (one string)")
     args = ap.parse_args()
@@ -232,6 +235,15 @@ def main():
             log(out, "value check %d failed:\n%s" % (k, res.stderr[-2000:]))
             raise SystemExit(2)
         log(out, "model-%03i on model-%03i-0.json: %s" % (k, k, res.stdout.strip().splitlines()[-1]))
+    if args.precision_positions > 0:
+        last = args.iterations + 1
+        log(out, "")
+        log(out, "reduced precision in the search of the TRAINED net model-%03i (tools/precision_in_the_loop.py: %d mid-game "
+                 "positions, 400 sims, bf16 / f16 tower against the f32 tower, same seeds, no root noise):" % (last, args.precision_positions))
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "precision_in_the_loop.py"), "--positions",
+                              str(args.precision_positions), "--network", model_path(args.prefix, last)], cwd=ROOT,
+                             capture_output=True, text=True)
+        log(out, res.stdout.strip().splitlines()[-1] if res.returncode == 0 else "failed:\n" + res.stderr[-2000:])
 
 
 if __name__ == "__main__":

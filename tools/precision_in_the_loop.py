@@ -3,7 +3,7 @@
 searched with the f32, bf16 and f16 towers — same Philox seeds, same sims/move, no Dirichlet noise so the evaluator
 is the only difference — and the root visit distributions are compared.
 
-    python tools/precision_in_the_loop.py [--positions 256] [--visits 400] [--blocks 12]
+    python tools/precision_in_the_loop.py [--positions 256] [--visits 400] [--blocks 12] [--network trained.npy]
 
 Prints one JSON object: per dtype, top-1 (most visited move) agreement with the f32 search, mean / p95 / max
 KL(f32 || dtype) of the root visit distributions and mean total-variation distance, plus max |dlogit| / |dvalue| on
@@ -78,15 +78,17 @@ def main():
     ap.add_argument("--visits", type=int, default=400)
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--network", help="weights to search with (.npy); default: a random-init net, seed 1")
     args = ap.parse_args()
     link.require_gpu()
     blockers = selfplay.parse_fen(selfplay.START_FEN_SELFPLAY)[2]
-    conv, bn = model.random_init(args.blocks, 128, seed=1)
+    conv, bn = model.load_model(args.network) if args.network else model.random_init(args.blocks, 128, seed=1)
     net = link.Net(conv, bn)
     pos = midgame_positions(args.positions, args.seed, blockers)
     lb = np.array([[x, o] if t == 0 else [o, x] for x, o, t in pos], dtype=np.uint64)
     p32, v32 = net.forward(lb, blockers, link.DTYPE_F32)
-    report = {"positions": len(pos), "visits": args.visits, "net": "%dx128 random-init seed 1" % args.blocks,
+    report = {"positions": len(pos), "visits": args.visits,
+              "net": os.path.basename(args.network) if args.network else "%dx128 random-init seed 1" % args.blocks,
               "logit_scale": float(np.abs(p32).max())}
     ref = root_distribution(net, link.DTYPE_F32, pos, blockers, args.visits, args.seed)
     # the search's own noise floor: f32 against f32 with nothing changed must be exact
