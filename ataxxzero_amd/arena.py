@@ -20,7 +20,7 @@ from . import link, model, selfplay
 
 
 class Match:
-    def __init__(self, weights_a, weights_b, visits, games=1024, dtype="bf16", seed=selfplay.DEFAULT_SEED,
+    def __init__(self, weights_a, weights_b, visits, games=1024, dtype="f16", seed=selfplay.DEFAULT_SEED,
                  max_plies=400):
         if games % 2:
             raise ValueError("the number of concurrent games must be even (each pairing is played both ways)")

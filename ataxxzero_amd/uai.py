@@ -96,7 +96,7 @@ class Position:
 class Searcher:
     TIME_CAP_VISITS = 20000  # arena size of a time-controlled search
 
-    def __init__(self, network_path, dtype="bf16", symmetry_average=False):
+    def __init__(self, network_path, dtype="f16", symmetry_average=False):
         # symmetry_average: every evaluation is nn_evals.evaluate (nn_evals.py:48-62); with one game the
         # eight images ride in the same tower launch, so it costs no time
         self.extra_flags = link.FLAG_SYMMETRY_AVG if symmetry_average else 0

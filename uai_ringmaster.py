@@ -46,7 +46,9 @@ if __name__ == "__main__":
         flag("--game-count", "size of the match (extension: the reference never stops): the games with uid below N are "
                              "played to completion and scored", type=int, default=1000, metavar="N"),
         flag("--concurrent", "games in flight on the GPU (extension)", type=int, metavar="N"),
-        flag("--dtype", "tower arithmetic (extension)", default="bf16", choices=["bf16", "f16", "f32"]),
+        flag("--dtype", "tower arithmetic (extension).  Match play defaults to f16: with a trained net the f16 search picks the f32 "
+                        "search's move in 100 %% of test positions, bf16 in 96 %% (DESIGN.md section 5); bf16 is 3-6 %% faster",
+             default="f16", choices=["bf16", "f16", "f32"]),
         flag("--seed", "Philox seed (extension)", type=int, default=selfplay.DEFAULT_SEED),
     ])
     print("Options:", args)
