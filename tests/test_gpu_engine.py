@@ -410,6 +410,37 @@ def test_uid_ordered_emission_is_an_unbiased_prefix():
     assert np.mean(first_finishers) < np.mean(prefix) + 1e-9 and np.mean(first_finishers) < np.mean(lengths_all)
 
 
+def test_lost_records_do_not_stall_uid_ordered_emission():
+    """The record ring holds what finishes between two drains (64 KiB per slot, at least 16 MiB).  A host that does not
+    drain for far too long loses records (AZH_STAT_RING_OVERFLOW counts them, the CLI exits non-zero on it).  In uid
+    order a lost uid would be waited for for ever: instead the order is given up from that drain on — everything held
+    is handed out and later games come as they arrive."""
+    conv, bn = model.random_init(1, 128, seed=12)
+    net = link.Net(conv, bn)
+    ocfg = orc.make_config(512, 2, seed=6, max_plies=400)
+    ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+    ge.set_emit_order(True)
+    for _ in range(40):                       # ~16 k games of ~1.5 k words each without a single drain: 4 M words overflow
+        ge.run(net, 500, link.DTYPE_BF16)
+        ge.sync()
+        if ge.stats()["ring_overflow"] > 0:
+            break
+    st = ge.stats()
+    assert st["ring_overflow"] > 0, st
+    first = ge.drain_json()
+    assert len(first) > 1000                  # what did fit comes out at once, gaps or not
+    later = []
+    for _ in range(6):
+        ge.run(net, 300, link.DTYPE_BF16)
+        later += ge.drain_json()
+    st2 = ge.stats()
+    # no stall: the games that finished after the overflow drain are all handed out
+    assert st2["ring_overflow"] == st["ring_overflow"] and len(later) == st2["games"] - st["games"] > 100
+    for line in (first[:5] + later[:5]):
+        entry = json.loads(line)
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+
+
 def test_loaded_positions_hook_matches_oracle():
     # azh_engine_set_positions (bench.py's steady-state set-up): every slot restarts at a mid-game position and ply; those
     # games are played and counted but not written; the slot's next game is an ordinary one
