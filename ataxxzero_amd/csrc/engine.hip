@@ -3,15 +3,21 @@
 //
 // Replaces the worker threads of the reference's cpp/self_play_client.cpp
 // (file:line under /root/reference):
-//   k_select   PUCT descent + expansion      MCTS::select_principal_variation :386-417,
-//                                            MCTSNode::select_action :333-366,
-//                                            total_action_score :310-324, step() :419-447
-//   k_backup   priors, root noise, backup    Evaluations::populate :204-271, step() :449-459
-//   k_advance  sample, record, re-root       sample_proportionally_to_visits :495-506,
-//                                            generate_game :526-578, MCTS::play :475-492
-// One search iteration = k_select -> k_compact -> (net) -> k_backup -> k_advance;
-// each game contributes exactly one leaf per iteration, so the per-iteration
-// evaluation batch is the number of concurrent games.
+//   select_game   PUCT descent + expansion      MCTS::select_principal_variation :386-417,
+//                                               MCTSNode::select_action :333-366,
+//                                               total_action_score :310-324, step() :419-447
+//   backup_game   priors, root noise, backup    Evaluations::populate :204-271, step() :449-459
+//   mark_game     "is the move due?"            generate_game :522-525
+//   advance_game  sample, record, re-root       sample_proportionally_to_visits :495-506,
+//                                               generate_game :526-578, MCTS::play :475-492
+// Each game contributes exactly one leaf per search iteration, so the per-iteration evaluation
+// batch is the number of concurrent games.  The device-resident loop (run_loop) runs an
+// iteration as TWO launches on one stream — the fused tower, then k_tree = backup + mark + the
+// next select + the leaf-list compaction, one wave per game, four games per workgroup — with the
+// queued re-roots (k_advance_list) on a side stream under the next tower.  The step-wise API
+// (azh_engine_select / _backup, used by the lock-step parity tests and the reference ABI) runs
+// the same device functions as separate kernels: k_select -> k_compact -> k_advance_list ->
+// (evaluator) -> k_backup -> k_mark.
 //
 // HBM layout (per game, two ping-pong arenas so re-rooting compacts by copying):
 //   node_board [2][G][node_cap]  16 B  x stones | turn<<63, o stones

@@ -417,10 +417,10 @@ def test_lost_records_do_not_stall_uid_ordered_emission():
     is handed out and later games come as they arrive."""
     conv, bn = model.random_init(1, 128, seed=12)
     net = link.Net(conv, bn)
-    ocfg = orc.make_config(512, 2, seed=6, max_plies=400)
+    ocfg = orc.make_config(256, 4, seed=6, max_plies=400)
     ge = link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
     ge.set_emit_order(True)
-    for _ in range(40):                       # ~16 k games of ~1.5 k words each without a single drain: 4 M words overflow
+    for _ in range(150):                      # ~3 k games of ~1.5 k words each without a single drain: the 4 M words overflow
         ge.run(net, 500, link.DTYPE_BF16)
         ge.sync()
         if ge.stats()["ring_overflow"] > 0:
