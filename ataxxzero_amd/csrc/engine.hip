@@ -49,7 +49,10 @@ constexpr int REC_STRIDE_WORDS = REC_HDR_WORDS + REC_MAXD;
 constexpr u32 RING_MAGIC = 0x415A4847u;  // "AZHG"
 constexpr int NSTAT = AZH_STAT_COUNT;
 constexpr int BFS_QL = 384;  // re-root frontier entries kept in LDS; later ones spill to bfs_spill in HBM
-constexpr int TREE_WAVES = 4;  // games (one wave each) per workgroup of the fused tree kernel
+#ifndef AZH_TREE_WAVES
+#define AZH_TREE_WAVES 4
+#endif
+constexpr int TREE_WAVES = AZH_TREE_WAVES;  // games (one wave each) per workgroup of the fused tree kernel
 constexpr int TREE_THREADS = TREE_WAVES * WAVE;
 // stamps of the diagnostic k_tree<true> (azh_engine_tree_stamps): wave start, state loaded, backup done, mark done,
 // descent done (leaf edge chosen / parked / terminal), expansion done, state stored, workgroup done (all four games)
