@@ -90,6 +90,8 @@ struct EngineParams {
     int *leaf_list2;   // arena: leaves of the games whose mover is net B
     int *leaf_count2;
     int *tree_done;    // tickets of the workgroups of a k_tree launch (the last one compacts the leaf list)
+    u32 *need_mask;    // [2][mask_words] one bit per game: its leaf goes to the net (row 1: to net B, arena); set by
+    int mask_words;    // k_tree's workgroups with one atomic OR each, read and cleared by the workgroup that finishes last
     u64 *stamps;       // diagnostic instantiation of k_tree only: [G][TREE_STAMPS] s_memrealtime readings (100 MHz)
     float *logits;
     float *values;
@@ -314,8 +316,9 @@ __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
 // ------------------------------------------------------------------ select + expand
 
 // `s` is the game's state, held in registers by the caller (the same values in all 64 lanes); written back here.
+// Returns what the leaf needs: 0 nothing, 1 an evaluation (by net A), 2 an evaluation by net B (arena).
 template <bool STAMP = false>
-__device__ inline void select_game(const EngineParams &P, int g, azh_game_state &s, u16 *s_moves, u64 *st = nullptr)
+__device__ inline int select_game(const EngineParams &P, int g, azh_game_state &s, u16 *s_moves, u64 *st = nullptr)
 {
     const int lane = lane_id();
     Arena A = arena_of(P, s.arena, g);
@@ -541,13 +544,12 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
         st[8] = st_levels;
         st[9] = st_children;
     }
+    int need = (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) ? 1 : 0;
+    if (need && (P.flags & AZH_FLAG_TWO_NETS))
+        need = 1 + ((s.ply + g) & 1);  // net A (1) / net B (2) is to move; even slots give x to A
     if (lane == 0) {
         P.gs[g] = s;
-        int need = (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) ? 1 : 0;
-        if (need && (P.flags & AZH_FLAG_TWO_NETS))
-            need = 1 + ((s.ply + g) & 1);  // net A (1) / net B (2) is to move; even slots give x to A
-        // write-through (agent scope): the workgroup that finishes last reads every game's flag (compact_leaves)
-        __hip_atomic_store(&P.need_eval[g], need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        P.need_eval[g] = need;
         P.leaf_board[g] = make_ulonglong2(leaf_mover, leaf_opp);
         if (over)
             P.force[g] = 1;
@@ -564,6 +566,7 @@ __device__ inline void select_game(const EngineParams &P, int g, azh_game_state 
         if (lane < NSTAT)
             add_stat(P, g, lane, inc);
     }
+    return need;
 }
 
 // Dense, game-ordered list of the games whose leaf needs the evaluator.
@@ -1160,19 +1163,23 @@ __global__ __launch_bounds__(WAVE) void k_advance_list(EngineParams P)
 }
 
 // The dense, game-ordered leaf list(s) of k_compact, written inside the tree launch by the workgroup that finishes
-// last (each workgroup draws a ticket from an agent-scope counter once its games have stored their flags; the flags
-// are stored and loaded write-through / L1-bypassing, so no fence is needed: MI355X_MICROARCH.md, hand-off forms).
-// One kernel and one kernel boundary less per search iteration.
+// last.  Every workgroup ORs its games' need bits into a bit mask (one returning agent-scope atomic per workgroup,
+// performed before it draws its ticket from an agent-scope counter); the workgroup whose ticket is the last reads the
+// mask — 16 bytes per 128 games — expands it in game order and clears it for the next launch.  Atomics and L1-bypassing
+// loads on both sides, so no fence is needed (MI355X_MICROARCH.md, hand-off forms).  One kernel and one kernel boundary
+// less per search iteration, and a tail of about a microsecond whatever the number of games.
 __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt /* [2][TREE_WAVES] */)
 {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int c = (P.G + TREE_THREADS - 1) / TREE_THREADS;  // consecutive games per thread
-    const int lo = min(P.G, t * c), hi = min(P.G, lo + c);
+    const int nw = P.mask_words;
+    const int c = (nw + TREE_THREADS - 1) / TREE_THREADS;  // consecutive mask words per thread (1 up to 8192 games)
+    const int lo = min(nw, t * c), hi = min(nw, lo + c);
+    u32 *m1p = P.need_mask, *m2p = P.need_mask + nw;
     int n1 = 0, n2 = 0;
-    for (int i = lo; i < hi; i++) {
-        const int v = __hip_atomic_load(&P.need_eval[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        n1 += two ? v == 1 : v != 0;
-        n2 += two && v == 2;
+    for (int k = lo; k < hi; k++) {
+        n1 += __popc(__hip_atomic_load(&m1p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (two)
+            n2 += __popc(__hip_atomic_load(&m2p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     const int i1 = wave_incl_scan(n1), i2 = wave_incl_scan(n2);
     if (lane == WAVE - 1) {
@@ -1188,12 +1195,19 @@ __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt
         t1 += s_cnt[k];
         t2 += s_cnt[TREE_WAVES + k];
     }
-    for (int i = lo; i < hi; i++) {
-        const int v = __hip_atomic_load(&P.need_eval[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (two ? v == 1 : v != 0)
-            P.leaf_list[b1++] = i;
-        if (two && v == 2)
-            P.leaf_list2[b2++] = i;
+    for (int k = lo; k < hi; k++) {
+        u32 m = __hip_atomic_load(&m1p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m)
+            __hip_atomic_store(&m1p[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (; m; m &= m - 1)
+            P.leaf_list[b1++] = 32 * k + (__ffs((int)m) - 1);
+        if (two) {
+            u32 m2 = __hip_atomic_load(&m2p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (m2)
+                __hip_atomic_store(&m2p[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (; m2; m2 &= m2 - 1)
+                P.leaf_list2[b2++] = 32 * k + (__ffs((int)m2) - 1);
+        }
     }
     if (t == 0) {
         *P.leaf_count = t1;
@@ -1212,10 +1226,13 @@ __global__ __launch_bounds__(TREE_THREADS) void k_tree(EngineParams P, int mode,
 {
     __shared__ u16 s_moves[TREE_WAVES][MAX_MOVES];  // per game: the move list of the node being expanded
     __shared__ int s_cnt[2 * TREE_WAVES];
+    __shared__ int s_need[TREE_WAVES];
     __shared__ int s_last;
+    static_assert(32 % TREE_WAVES == 0, "a workgroup's need bits must lie in one word of the mask");
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the game's addresses are scalars
     const int g = blockIdx.x * TREE_WAVES + w;
     u64 st[TREE_STAMPS] = {};
+    int need = 0;
     if constexpr (STAMP) st[0] = tree_stamp();
     if (g < P.G) {
         azh_game_state s = P.gs[g];
@@ -1231,13 +1248,14 @@ __global__ __launch_bounds__(TREE_THREADS) void k_tree(EngineParams P, int mode,
             if (!(mode & 1)) st[2] = st[3];
         }
         if (mode & 2)
-            select_game<STAMP>(P, g, s, s_moves[w], st);  // stores the state
+            need = select_game<STAMP>(P, g, s, s_moves[w], st);  // stores the state
         else if (lane_id() == 0)
             P.gs[g] = s;
     }
     if (!(mode & 2))
         return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's flag has left the CU
+    if (lane_id() == 0)
+        s_need[w] = need;
     if constexpr (STAMP) st[6] = tree_stamp();
     __syncthreads();
     if constexpr (STAMP) {
@@ -1250,8 +1268,25 @@ __global__ __launch_bounds__(TREE_THREADS) void k_tree(EngineParams P, int mode,
             P.stamps[(size_t)g * TREE_STAMPS + lane_id()] = v;
         }
     }
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+        u32 m1 = 0, m2 = 0;
+#pragma unroll
+        for (int k = 0; k < TREE_WAVES; k++) {
+            const int v = s_need[k];
+            m1 |= (u32)(two ? v == 1 : v != 0) << k;
+            m2 |= (u32)(two && v == 2) << k;
+        }
+        const int g0 = blockIdx.x * TREE_WAVES;
+        u32 seen = 0;
+        if (m1)
+            seen |= __hip_atomic_fetch_or(&P.need_mask[g0 >> 5], m1 << (g0 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m2)
+            seen |= __hip_atomic_fetch_or(&P.need_mask[P.mask_words + (g0 >> 5)], m2 << (g0 & 31), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+        // the ORs have returned, i.e. have been performed, before the ticket is drawn
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(seen) : "memory");
         s_last = __hip_atomic_fetch_add(P.tree_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
     __syncthreads();
     if (s_last)
         compact_leaves(P, two, s_cnt);
@@ -1408,6 +1443,8 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.leaf_list2, G);
     rc |= dev_alloc(e, &P.leaf_count2, 1);
     rc |= dev_alloc(e, &P.tree_done, 1);
+    P.mask_words = (P.G + 31) / 32;
+    rc |= dev_alloc(e, &P.need_mask, 2 * (size_t)P.mask_words);
     rc |= dev_alloc(e, &P.logits, G * AZH_POLICY_SIZE);
     rc |= dev_alloc(e, &P.values, G);
     rc |= dev_alloc(e, &P.rec, G * P.max_plies * REC_STRIDE_WORDS);
