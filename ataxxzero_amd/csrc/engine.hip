@@ -49,11 +49,17 @@ constexpr int REC_STRIDE_WORDS = REC_HDR_WORDS + REC_MAXD;
 constexpr u32 RING_MAGIC = 0x415A4847u;  // "AZHG"
 constexpr int NSTAT = AZH_STAT_COUNT;
 constexpr int BFS_QL = 384;  // re-root frontier entries kept in LDS; later ones spill to bfs_spill in HBM
-#ifndef AZH_TREE_WAVES
-#define AZH_TREE_WAVES 4
+// Games (one wave each) per workgroup of the fused tree kernel.  Up to 8192 games every game wave is resident at once (8
+// waves per SIMD) and the number hardly matters (tree phase 0.084-0.086 ms for 2 / 4 / 8 / 16 at 4096 games; 0.092 for 1: one
+// ticket and one atomic OR per game); beyond that the waves come in rounds, and a workgroup gives its slots back only when
+// its slowest game is done: at 16384 games 0.203 ms with 2 per workgroup, 0.222 with 4, 0.233 with 8, 0.311 with 16, 0.253
+// with 1 (tools/tree_waves_sweep.sh, profiles/round3_tree_waves_sweep.txt).  -DAZH_TREE_WAVES=n forces one value.
+#ifdef AZH_TREE_WAVES
+constexpr int TREE_WAVES_SMALL = AZH_TREE_WAVES, TREE_WAVES_LARGE = AZH_TREE_WAVES;
+#else
+constexpr int TREE_WAVES_SMALL = 4, TREE_WAVES_LARGE = 2;
 #endif
-constexpr int TREE_WAVES = AZH_TREE_WAVES;  // games (one wave each) per workgroup of the fused tree kernel
-constexpr int TREE_THREADS = TREE_WAVES * WAVE;
+constexpr int TREE_ONE_ROUND_GAMES = 8192;  // 8 waves x 4 SIMDs x 256 CUs
 // stamps of the diagnostic k_tree<true> (azh_engine_tree_stamps): wave start, state loaded, backup done, mark done,
 // descent done (leaf edge chosen / parked / terminal), expansion done, state stored, workgroup done (all four games)
 constexpr int TREE_STAMPS = 10;  // + [8] levels descended, [9] children scanned in this launch
@@ -1168,8 +1174,10 @@ __global__ __launch_bounds__(WAVE) void k_advance_list(EngineParams P)
 // mask — 16 bytes per 128 games — expands it in game order and clears it for the next launch.  Atomics and L1-bypassing
 // loads on both sides, so no fence is needed (MI355X_MICROARCH.md, hand-off forms).  One kernel and one kernel boundary
 // less per search iteration, and a tail of about a microsecond whatever the number of games.
+template <int TREE_WAVES>
 __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt /* [2][TREE_WAVES] */)
 {
+    constexpr int TREE_THREADS = TREE_WAVES * WAVE;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nw = P.mask_words;
     const int c = (nw + TREE_THREADS - 1) / TREE_THREADS;  // consecutive mask words per thread (1 up to 8192 games)
@@ -1221,8 +1229,8 @@ __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt
 // the next select, with the game's state in registers throughout; TREE_WAVES games share a workgroup (each wave on
 // its own: wave_sync, never a workgroup barrier, inside a game), and the last workgroup to finish compacts the leaf
 // list.  mode bit 0: backup + mark, bit 1: select (+ compaction).
-template <bool STAMP>
-__global__ __launch_bounds__(TREE_THREADS) void k_tree(EngineParams P, int mode, int two)
+template <bool STAMP, int TREE_WAVES>
+__global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int mode, int two)
 {
     __shared__ u16 s_moves[TREE_WAVES][MAX_MOVES];  // per game: the move list of the node being expanded
     __shared__ int s_cnt[2 * TREE_WAVES];
@@ -1289,7 +1297,7 @@ __global__ __launch_bounds__(TREE_THREADS) void k_tree(EngineParams P, int mode,
     }
     __syncthreads();
     if (s_last)
-        compact_leaves(P, two, s_cnt);
+        compact_leaves<TREE_WAVES>(P, two, s_cnt);
 }
 
 // Reference feature rows for the dense leaf list (cpp/self_play_client.cpp:174-202).
@@ -1649,9 +1657,21 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
     if (iterations <= 0)
         return 0;
     const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
-    const dim3 tree_grid((e->P.G + TREE_WAVES - 1) / TREE_WAVES);
-    hipExtLaunchKernelGGL(k_tree<false>, tree_grid, dim3(TREE_THREADS), 0, e->stream, nullptr, e->ev_sel, 0, e->P, 2,
-                          two);  // select + leaf list
+    // one fused tree launch; ev (or nullptr) is signalled by the kernel's own completion
+    auto launch_tree = [&](bool stamped, int mode, hipEvent_t ev) {
+        const bool small = e->P.G <= TREE_ONE_ROUND_GAMES;
+        const int waves = small ? TREE_WAVES_SMALL : TREE_WAVES_LARGE;
+        const dim3 grid((e->P.G + waves - 1) / waves), block(waves * WAVE);
+        if (stamped && small)
+            hipExtLaunchKernelGGL((k_tree<true, TREE_WAVES_SMALL>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
+        else if (stamped)
+            hipExtLaunchKernelGGL((k_tree<true, TREE_WAVES_LARGE>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
+        else if (small)
+            hipExtLaunchKernelGGL((k_tree<false, TREE_WAVES_SMALL>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
+        else
+            hipExtLaunchKernelGGL((k_tree<false, TREE_WAVES_LARGE>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
+    };
+    launch_tree(false, 2, e->ev_sel);  // select + leaf list
     // queued re-roots run on the side stream, under the tower that follows; the next tree launch waits for them
     // (ev_sel is signalled by the tree launch itself, ev_adv by the re-root launch: hipExtLaunchKernelGGL's stop event —
     // the two event-record packets that used to sit at the kernel boundaries of the main stream are gone)
@@ -1682,11 +1702,10 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         const int last = it + 1 == iterations;
         AZH_HIP(hipStreamWaitEvent(e->stream, e->ev_adv, 0));
         if (e->stamp_next && !last) {
-            hipExtLaunchKernelGGL(k_tree<true>, tree_grid, dim3(TREE_THREADS), 0, e->stream, nullptr, e->ev_sel, 0, e->P, 3, two);
+            launch_tree(true, 3, e->ev_sel);
             e->stamp_next = false;
         } else {
-            hipExtLaunchKernelGGL(k_tree<false>, tree_grid, dim3(TREE_THREADS), 0, e->stream, nullptr,
-                                  last ? nullptr : e->ev_sel, 0, e->P, last ? 1 : 3, two);
+            launch_tree(false, last ? 1 : 3, last ? nullptr : e->ev_sel);
         }
         AZH_HIP(hipGetLastError());
         if (!last && side_advance()) return -1;
