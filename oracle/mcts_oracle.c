@@ -42,6 +42,7 @@ struct orc_engine {
     blob *done_head, *done_tail;
     int done_count;
     int32_t *no_emit;  /* [G] the slot's current game was started by orc_engine_set_positions: counted, not written */
+    uint32_t uid_limit; /* orc_engine_set_game_limit: games with uid >= this are not started (0 = no limit) */
     uint32_t *tt;      /* ORC_FLAG_EVAL_CACHE: [2][G][tt_size] open-addressed table of evaluated nodes, keyed by the board */
     int tt_size;
 };
@@ -174,6 +175,16 @@ static int make_node(orc_engine *e, int g, int a, int id, const orc_pos *p, int 
 static void init_game(orc_engine *e, int g, uint32_t uid)
 {
     orc_game_state *s = &e->gs[g];
+    if (e->uid_limit != 0 && uid >= e->uid_limit) {
+        /* past the game limit (azh_engine_set_game_limit): no game, the slot goes idle; the arena stays as the last move left it */
+        s->phase = ORC_PHASE_IDLE;
+        s->uid = uid;
+        s->leaf_kind = ORC_LEAF_NONE;
+        s->path_len = 0;
+        s->root_visits = 0;
+        e->force[g] = 0;
+        return;
+    }
     memset(s, 0, sizeof(*s));
     s->uid = uid;
     s->phase = ORC_PHASE_ROOT_EVAL;
@@ -229,6 +240,14 @@ void orc_engine_destroy(orc_engine *e)
 
 int orc_engine_node_cap(const orc_engine *e) { return e->node_cap; }
 void orc_engine_set_visits(orc_engine *e, int visits) { e->cfg.visits = visits; }
+/* mirror of azh_engine_set_game_limit: uids 0 .. games - 1 are played; a slot whose (next) game is past that goes idle */
+void orc_engine_set_game_limit(orc_engine *e, int64_t games)
+{
+    e->uid_limit = (uint32_t)games;
+    for (int g = 0; g < e->G; g++)
+        if (e->gs[g].uid >= e->uid_limit)
+            e->gs[g].phase = ORC_PHASE_IDLE;
+}
 /* mirror of azh_engine_set_positions: every slot restarts at boards[g] (x | turn << 63, o) / plies[g], fresh tree, uid = g */
 void orc_engine_set_positions(orc_engine *e, const uint64_t *boards, const int32_t *plies)
 {
@@ -259,10 +278,10 @@ static void select_game(orc_engine *e, int g)
     const int resume = s->leaf_kind == ORC_LEAF_DESCENT;
     if (!resume)
         s->path_len = 0;
-    if (s->phase == ORC_PHASE_ADVANCING) {
+    if (s->phase == ORC_PHASE_ADVANCING || s->phase == ORC_PHASE_IDLE) {
         s->leaf_kind = ORC_LEAF_NONE;
         s->leaf_node = 0;
-        return; /* orc_engine_select plays the move after the leaf pass */
+        return; /* ADVANCING: orc_engine_select plays the move after the leaf pass; IDLE: nothing to search */
     }
     if (s->phase == ORC_PHASE_ROOT_EVAL) {
         if ((e->cfg.flags & ORC_FLAG_TWO_NETS) && (NI(e, a, g)[1] & 0xFFFFu) == 1) {

@@ -53,7 +53,8 @@ enum { ORC_LEAF_NONE = 0, ORC_LEAF_EVAL = 1, ORC_LEAF_TERMINAL = 2, ORC_LEAF_ROO
 /* ORC_PHASE_ADVANCING: the move is due (root visits reached the threshold at the last backup).  The next select
  * gives the game no leaf and then plays the move (sampling, record, re-root): in the HIP engine the re-root runs
  * in its own launch beside the evaluator, so the iteration structure is part of the engine/oracle contract. */
-enum { ORC_PHASE_ROOT_EVAL = 0, ORC_PHASE_SEARCH = 1, ORC_PHASE_ADVANCING = 2 };
+enum { ORC_PHASE_ROOT_EVAL = 0, ORC_PHASE_SEARCH = 1, ORC_PHASE_ADVANCING = 2,
+       ORC_PHASE_IDLE = 3 /* the slot's next game is past the game limit: no leaf, no move */ };
 
 /* per-game scalar state, same field order as the HIP engine's snapshot */
 typedef struct {
@@ -86,6 +87,8 @@ int orc_engine_edge_cap(const orc_engine *e);
 /* root-visit threshold for the coming moves, 1 .. the value the engine was created with (the arenas are sized for
  * that); mirror of azh_engine_set_visits */
 void orc_engine_set_visits(orc_engine *e, int visits);
+/* mirror of azh_engine_set_game_limit (call before the first iteration) */
+void orc_engine_set_game_limit(orc_engine *e, int64_t games);
 /* mirror of azh_engine_set_positions: every slot restarts at boards[g] (x | turn << 63, o) / plies[g] with a fresh tree;
  * such games are counted, not written */
 void orc_engine_set_positions(orc_engine *e, const uint64_t *boards, const int32_t *plies);

@@ -76,6 +76,7 @@ def lib():
         "orc_engine_node_cap": (ctypes.c_int, [vp]), "orc_engine_edge_cap": (ctypes.c_int, [vp]),
         "orc_engine_set_visits": (None, [vp, ctypes.c_int]),
         "orc_engine_set_positions": (None, [vp, vp, vp]),
+        "orc_engine_set_game_limit": (None, [vp, ctypes.c_int64]),
         "orc_engine_select": (ctypes.c_int, [vp, vp]), "orc_engine_leaf_boards": (None, [vp, vp]),
         "orc_engine_leaf_features": (None, [vp, ctypes.c_int, vp]),
         "orc_engine_backup": (None, [vp, vp, vp]),
@@ -209,6 +210,9 @@ class Engine:
 
     def set_visits(self, visits):
         lib().orc_engine_set_visits(self.h, visits)
+
+    def set_game_limit(self, games):
+        lib().orc_engine_set_game_limit(self.h, int(games))
 
     def set_positions(self, boards, plies):
         boards = np.ascontiguousarray(boards, dtype=np.uint64).reshape(self.G, 2)

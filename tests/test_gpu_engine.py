@@ -156,6 +156,19 @@ def test_game_limit_plays_exactly_the_games_below_it_and_then_idles():
         limited.set_game_limit(0)
 
 
+def test_game_limit_matches_oracle_in_lockstep():
+    # the same rule in the oracle (orc_engine_set_game_limit): slots idle at the same iteration, states and trees equal
+    oe, ge = make_pair(games=12, visits=6, max_plies=90, seed=4)
+    oe.set_game_limit(30)
+    ge.set_game_limit(30)
+    o_games, g_lines = run_lockstep(oe, ge, 2500, check_every=37)
+    so, sg = oe.stats(), ge.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    assert so["games"] + so["dropped"] == 30 and so["dropped"] > 0 and len(g_lines) == len(o_games) == so["games"]
+    assert all(ge.game_state(g).phase == 3 for g in range(12))
+
+
 def test_reroot_queue_spill_path_matches_oracle():
     # visits > 512: kept subtrees grow past the LDS part of the re-root frontier queue, so the
     # HBM spill path of advance_game is exercised; still bit-exact against the oracle
