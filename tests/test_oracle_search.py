@@ -207,3 +207,26 @@ def test_evaluation_cache_changes_no_tree():
     assert sa["steps"] == sb["steps"] and sa["plies"] == sb["plies"] >= 60
     assert sb["cache_hits"] > 0 and sb["nn_evals"] + sb["cache_hits"] == sa["nn_evals"] and asked_b < asked_a
     # (few with this peaked synthetic evaluator; about a quarter of the expansions with a real net: tools/leaf_duplicates.py)
+
+
+def test_game_limit_plays_exactly_the_games_below_it():
+    # orc_engine_set_game_limit (mirror of azh_engine_set_game_limit): uids 0 .. N - 1 and nothing else; slots idle afterwards
+    from tests.helpers import synthetic_evals
+    e = orc.Engine(orc.make_config(8, 4, seed=3, max_plies=60))
+    e.set_game_limit(20)
+    uids = set()
+    for _ in range(4000):
+        _, need = e.select()
+        uids |= {e.game_state(g).uid for g in range(8) if e.game_state(g).phase != 3}
+        lg, v = synthetic_evals(e.leaf_boards())
+        e.backup(lg, v)
+        st = e.stats()
+        if st["games"] + st["dropped"] >= 20:
+            break
+    assert st["games"] + st["dropped"] == 20 and uids == set(range(20))
+    assert all(e.game_state(g).phase == 3 and e.game_state(g).uid >= 20 for g in range(8))
+    n, need = e.select()
+    assert n == 0 and not need.any()
+    lg, v = synthetic_evals(e.leaf_boards())
+    e.backup(lg, v)
+    assert e.stats() == st
