@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timeline of one steady-state iteration from rocprofv3's kernel trace of bench.py: durations and the gaps between
-# tower -> k_tree -> k_compact -> next tower (run on the GPU box from the repo root).
+# tower -> k_tree -> next tower, and of the side stream's re-root launch (run on the GPU box from the repo root).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/gap_trace
@@ -12,8 +12,8 @@ import csv, glob, sys, os
 f = max(glob.glob(os.path.join(sys.argv[1], "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]) for r in csv.DictReader(open(f))]
 rows.sort()
-main = [r for r in rows if r[2] in ("k_tower2", "k_tree", "k_compact")]
-tail = main[-3 * 300:]
+main = [r for r in rows if r[2] in ("k_tower2", "k_tree")]
+tail = main[-2 * 300:]
 import collections
 gaps = collections.defaultdict(list); durs = collections.defaultdict(list)
 for a, b in zip(tail, tail[1:]):
