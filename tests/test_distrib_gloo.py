@@ -82,7 +82,7 @@ def test_bench_py_eight_ranks_as_the_scaling_run_starts_them():
     """The rank count the round-end scaling run ends with: `bench.py --gpus 8` starts eight processes, eight distinct Philox
     seeds, one aggregate line with n_gpus 8 (units summed, max-over-ranks time).  The GPU work is replaced by fixed
     units: a GPU box admits six processes on its card, so the eight-process launch itself is rehearsed here, and the
-    GPU side of a many-rank launch with five ranks in tests/test_gpu_cli.py."""
+    GPU side of a many-rank launch with four ranks in tests/test_gpu_cli.py."""
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     t0 = time.time()

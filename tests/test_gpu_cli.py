@@ -369,9 +369,10 @@ def test_bench_py_two_ranks_on_one_gpu():
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["launches_timed"] > 0
 
 
-# A GPU box admits six processes on its card at once, this test process included: five ranks is the largest many-rank
+# A GPU box admits six processes on its card at once, this test process included: four ranks keep one slot in hand (a
+# run that exceeds the limit is killed as a whole); five were run during development.  Four is the many-rank
 # launch that can be rehearsed on the GPU (the eight-process launch itself: tests/test_distrib_gloo.py).
-MANY_RANKS = 5
+MANY_RANKS = 4
 
 
 def test_bench_py_many_ranks_on_one_gpu():
