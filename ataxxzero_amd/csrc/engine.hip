@@ -65,11 +65,8 @@ constexpr int TREE_ONE_ROUND_GAMES = 8192;  // 8 waves x 4 SIMDs x 256 CUs
 // iteration to the next (it follows its principal line), so every game leaves a hint — parked, >= 32, >= 12 levels, less
 // — and the next launch takes the games bucket by bucket, deepest first (longest job first: the makespan of 16384 games
 // on 8192 wave slots comes down from 2.8 to about 1.5 times the deepest descent).  Which wave plays a game does not
-// matter to the game, the leaf list stays game-ordered — but WHERE it is played matters to its latency: workgroup j runs
-// on XCD j % 8, and a game's upper tree levels sit in the L2 of the XCD that played it last (ordered over the whole chip a
-// level cost 1.7-2.2 us instead of 1.4).  So the order is kept per XCD: a game never leaves the XCD of its slot.
+// matter to the game; the leaf list stays game-ordered.
 constexpr int ORDER_BUCKETS = 4;
-constexpr int XCDS = 8;
 // stamps of the diagnostic k_tree<true> (azh_engine_tree_stamps): wave start, state loaded, backup done, mark done,
 // descent done (leaf edge chosen / parked / terminal), expansion done, state stored, workgroup done (all four games)
 constexpr int TREE_STAMPS = 10;  // + [8] levels descended, [9] children scanned in this launch
@@ -108,9 +105,8 @@ struct EngineParams {
     int *tree_done;    // tickets of the workgroups of a k_tree launch (the last one compacts the leaf list)
     u32 *need_mask;    // [2][mask_words] one bit per game: its leaf goes to the net (row 1: to net B, arena); set by
     int mask_words;    // k_tree's workgroups with one atomic OR each, read and cleared by the workgroup that finishes last
-    int *order_list;   // beyond TREE_ONE_ROUND_GAMES: [2][XCDS][ORDER_BUCKETS][order_cap] the games of each XCD in the order
-    int *order_count;  // the next tree launch takes them (deepest descents first), [2][XCDS][ORDER_BUCKETS] their numbers
-    int order_cap;     // (>= games per XCD); ping-pong per launch
+    int *order_list;   // beyond TREE_ONE_ROUND_GAMES: [2][ORDER_BUCKETS][G] the games in the order the next tree launch
+    int *order_count;  // takes them (deepest descents first), [2][ORDER_BUCKETS] their numbers; ping-pong per launch
     u64 *stamps;       // diagnostic instantiation of k_tree only: [G][TREE_STAMPS] s_memrealtime readings (100 MHz)
     float *logits;
     float *values;
@@ -1252,12 +1248,11 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
     static_assert(32 % TREE_WAVES == 0, "a workgroup's need bits must lie in one word of the mask");
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the game's addresses are scalars
     int g = blockIdx.x * TREE_WAVES + w;
-    const int xcd = (int)(blockIdx.x % XCDS);  // the XCD this workgroup runs on = the home of the games it may take
     if constexpr (ORDERED) {
-        // slot -> game through the order the previous launch left for this XCD (read_order = its parity, -1: none yet)
+        // slot -> game through the order the previous launch left (read_order = its parity, -1: none yet)
         if (read_order >= 0 && g < P.G) {
-            const int *cnt = P.order_count + (read_order * XCDS + xcd) * ORDER_BUCKETS;
-            int b = 0, pos = (int)(blockIdx.x / XCDS) * TREE_WAVES + w;  // this slot's rank among its XCD's slots
+            const int *cnt = P.order_count + read_order * ORDER_BUCKETS;
+            int b = 0, pos = g;
 #pragma unroll
             for (int k = 0; k < ORDER_BUCKETS - 1; k++) {
                 const int c = cnt[k];
@@ -1266,7 +1261,7 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
                     b = k + 1;
                 }
             }
-            g = P.order_list[((size_t)(read_order * XCDS + xcd) * ORDER_BUCKETS + b) * P.order_cap + pos];
+            g = P.order_list[((size_t)read_order * ORDER_BUCKETS + b) * P.G + pos];
         }
     }
     u64 st[TREE_STAMPS] = {};
@@ -1293,9 +1288,9 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
             if ((mode & 2) && lane_id() == 0) {
                 // the hint for the next launch, and this game's need bit (a workgroup's games are no neighbours here)
                 const int b = s.leaf_kind == AZH_LEAF_DESCENT ? 0 : (s.path_len >= 32 ? 1 : (s.path_len >= 12 ? 2 : 3));
-                int *cnt = P.order_count + (write_order * XCDS + xcd) * ORDER_BUCKETS;
+                int *cnt = P.order_count + write_order * ORDER_BUCKETS;
                 const int pos = __hip_atomic_fetch_add(&cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                P.order_list[((size_t)(write_order * XCDS + xcd) * ORDER_BUCKETS + b) * P.order_cap + pos] = g;
+                P.order_list[((size_t)write_order * ORDER_BUCKETS + b) * P.G + pos] = g;
                 u32 seen = 0;
                 const u32 bit = 1u << (g & 31);
                 if (need == 1 || (need && !two))
@@ -1347,8 +1342,8 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
         compact_leaves<TREE_WAVES>(P, two, s_cnt);
         if constexpr (ORDERED) {
             // every workgroup has read the order it was given: its counters are free for the launch after the next
-            if (threadIdx.x < XCDS * ORDER_BUCKETS)
-                P.order_count[(1 - write_order) * XCDS * ORDER_BUCKETS + threadIdx.x] = 0;
+            if (threadIdx.x < ORDER_BUCKETS)
+                P.order_count[(1 - write_order) * ORDER_BUCKETS + threadIdx.x] = 0;
         }
     }
 }
@@ -1508,9 +1503,8 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     P.mask_words = (P.G + 31) / 32;
     rc |= dev_alloc(e, &P.need_mask, 2 * (size_t)P.mask_words);
     if (P.G > TREE_ONE_ROUND_GAMES) {
-        P.order_cap = (P.G + XCDS - 1) / XCDS + 16;
-        rc |= dev_alloc(e, &P.order_list, 2 * (size_t)XCDS * ORDER_BUCKETS * P.order_cap);
-        rc |= dev_alloc(e, &P.order_count, 2 * XCDS * ORDER_BUCKETS);
+        rc |= dev_alloc(e, &P.order_list, 2 * (size_t)ORDER_BUCKETS * G);
+        rc |= dev_alloc(e, &P.order_count, 2 * ORDER_BUCKETS);
     }
     rc |= dev_alloc(e, &P.logits, G * AZH_POLICY_SIZE);
     rc |= dev_alloc(e, &P.values, G);
