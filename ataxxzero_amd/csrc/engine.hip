@@ -60,13 +60,6 @@ constexpr int TREE_WAVES_SMALL = AZH_TREE_WAVES, TREE_WAVES_LARGE = AZH_TREE_WAV
 constexpr int TREE_WAVES_SMALL = 4, TREE_WAVES_LARGE = 2;
 #endif
 constexpr int TREE_ONE_ROUND_GAMES = 8192;  // 8 waves x 4 SIMDs x 256 CUs
-// Beyond that the game waves of a tree launch come in rounds, and the launch lasts until the last wave to START has
-// finished: a deep descent that starts late is the whole tail.  How deep a game descends is much the same from one
-// iteration to the next (it follows its principal line), so every game leaves a hint — parked, >= 32, >= 12 levels, less
-// — and the next launch takes the games bucket by bucket, deepest first (longest job first: the makespan of 16384 games
-// on 8192 wave slots comes down from 2.8 to about 1.5 times the deepest descent).  Which wave plays a game does not
-// matter to the game; the leaf list stays game-ordered.
-constexpr int ORDER_BUCKETS = 4;
 // stamps of the diagnostic k_tree<true> (azh_engine_tree_stamps): wave start, state loaded, backup done, mark done,
 // descent done (leaf edge chosen / parked / terminal), expansion done, state stored, workgroup done (all four games)
 constexpr int TREE_STAMPS = 10;  // + [8] levels descended, [9] children scanned in this launch
@@ -105,8 +98,6 @@ struct EngineParams {
     int *tree_done;    // tickets of the workgroups of a k_tree launch (the last one compacts the leaf list)
     u32 *need_mask;    // [2][mask_words] one bit per game: its leaf goes to the net (row 1: to net B, arena); set by
     int mask_words;    // k_tree's workgroups with one atomic OR each, read and cleared by the workgroup that finishes last
-    int *order_list;   // beyond TREE_ONE_ROUND_GAMES: [2][ORDER_BUCKETS][G] the games in the order the next tree launch
-    int *order_count;  // takes them (deepest descents first), [2][ORDER_BUCKETS] their numbers; ping-pong per launch
     u64 *stamps;       // diagnostic instantiation of k_tree only: [G][TREE_STAMPS] s_memrealtime readings (100 MHz)
     float *logits;
     float *values;
@@ -1238,8 +1229,8 @@ __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt
 // the next select, with the game's state in registers throughout; TREE_WAVES games share a workgroup (each wave on
 // its own: wave_sync, never a workgroup barrier, inside a game), and the last workgroup to finish compacts the leaf
 // list.  mode bit 0: backup + mark, bit 1: select (+ compaction).
-template <bool STAMP, int TREE_WAVES, bool ORDERED = false>
-__global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int mode, int two, int read_order, int write_order)
+template <bool STAMP, int TREE_WAVES>
+__global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int mode, int two)
 {
     __shared__ u16 s_moves[TREE_WAVES][MAX_MOVES];  // per game: the move list of the node being expanded
     __shared__ int s_cnt[2 * TREE_WAVES];
@@ -1247,23 +1238,7 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
     __shared__ int s_last;
     static_assert(32 % TREE_WAVES == 0, "a workgroup's need bits must lie in one word of the mask");
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the game's addresses are scalars
-    int g = blockIdx.x * TREE_WAVES + w;
-    if constexpr (ORDERED) {
-        // slot -> game through the order the previous launch left (read_order = its parity, -1: none yet)
-        if (read_order >= 0 && g < P.G) {
-            const int *cnt = P.order_count + read_order * ORDER_BUCKETS;
-            int b = 0, pos = g;
-#pragma unroll
-            for (int k = 0; k < ORDER_BUCKETS - 1; k++) {
-                const int c = cnt[k];
-                if (b == k && pos >= c) {
-                    pos -= c;
-                    b = k + 1;
-                }
-            }
-            g = P.order_list[((size_t)read_order * ORDER_BUCKETS + b) * P.G + pos];
-        }
-    }
+    const int g = blockIdx.x * TREE_WAVES + w;
     u64 st[TREE_STAMPS] = {};
     int need = 0;
     if constexpr (STAMP) st[0] = tree_stamp();
@@ -1284,28 +1259,11 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
             need = select_game<STAMP>(P, g, s, s_moves[w], st);  // stores the state
         else if (lane_id() == 0)
             P.gs[g] = s;
-        if constexpr (ORDERED) {
-            if ((mode & 2) && lane_id() == 0) {
-                // the hint for the next launch, and this game's need bit (a workgroup's games are no neighbours here)
-                const int b = s.leaf_kind == AZH_LEAF_DESCENT ? 0 : (s.path_len >= 32 ? 1 : (s.path_len >= 12 ? 2 : 3));
-                int *cnt = P.order_count + write_order * ORDER_BUCKETS;
-                const int pos = __hip_atomic_fetch_add(&cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                P.order_list[((size_t)write_order * ORDER_BUCKETS + b) * P.G + pos] = g;
-                u32 seen = 0;
-                const u32 bit = 1u << (g & 31);
-                if (need == 1 || (need && !two))
-                    seen = __hip_atomic_fetch_or(&P.need_mask[g >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else if (need == 2)
-                    seen = __hip_atomic_fetch_or(&P.need_mask[P.mask_words + (g >> 5)], bit, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" : : "v"(seen) : "memory");  // performed before the workgroup's ticket
-            }
-        }
     }
     if (!(mode & 2))
         return;
     if (lane_id() == 0)
-        s_need[w] = ORDERED ? 0 : need;
+        s_need[w] = need;
     if constexpr (STAMP) st[6] = tree_stamp();
     __syncthreads();
     if constexpr (STAMP) {
@@ -1338,14 +1296,8 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
         s_last = __hip_atomic_fetch_add(P.tree_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     }
     __syncthreads();
-    if (s_last) {
+    if (s_last)
         compact_leaves<TREE_WAVES>(P, two, s_cnt);
-        if constexpr (ORDERED) {
-            // every workgroup has read the order it was given: its counters are free for the launch after the next
-            if (threadIdx.x < ORDER_BUCKETS)
-                P.order_count[(1 - write_order) * ORDER_BUCKETS + threadIdx.x] = 0;
-        }
-    }
 }
 
 // Reference feature rows for the dense leaf list (cpp/self_play_client.cpp:174-202).
@@ -1423,7 +1375,6 @@ struct azh_engine {
     bool selected = false;
     bool arena_lists = false;  // run_arena: one leaf list per net
     bool stamp_next = false;   // azh_engine_tree_stamps: the next fused tree launch of the loop is the stamped instantiation
-    int order_parity = -1;     // beyond TREE_ONE_ROUND_GAMES: which half of order_list the next tree launch reads (-1: none yet)
 };
 
 static const size_t MAX_TIMED_SAMPLES = 8192;
@@ -1502,10 +1453,6 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.tree_done, 1);
     P.mask_words = (P.G + 31) / 32;
     rc |= dev_alloc(e, &P.need_mask, 2 * (size_t)P.mask_words);
-    if (P.G > TREE_ONE_ROUND_GAMES) {
-        rc |= dev_alloc(e, &P.order_list, 2 * (size_t)ORDER_BUCKETS * G);
-        rc |= dev_alloc(e, &P.order_count, 2 * ORDER_BUCKETS);
-    }
     rc |= dev_alloc(e, &P.logits, G * AZH_POLICY_SIZE);
     rc |= dev_alloc(e, &P.values, G);
     rc |= dev_alloc(e, &P.rec, G * P.max_plies * REC_STRIDE_WORDS);
@@ -1715,21 +1662,14 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         const bool small = e->P.G <= TREE_ONE_ROUND_GAMES;
         const int waves = small ? TREE_WAVES_SMALL : TREE_WAVES_LARGE;
         const dim3 grid((e->P.G + waves - 1) / waves), block(waves * WAVE);
-        if (small) {
-            if (stamped)
-                hipExtLaunchKernelGGL((k_tree<true, TREE_WAVES_SMALL>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two, -1, -1);
-            else
-                hipExtLaunchKernelGGL((k_tree<false, TREE_WAVES_SMALL>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two, -1, -1);
-            return;
-        }
-        // more games than resident waves: the launch reads the order its predecessor left and leaves one itself
-        const int rd = e->order_parity, wr = rd < 0 ? 0 : 1 - rd;
-        if (stamped)
-            hipExtLaunchKernelGGL((k_tree<true, TREE_WAVES_LARGE, true>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two, rd, wr);
+        if (stamped && small)
+            hipExtLaunchKernelGGL((k_tree<true, TREE_WAVES_SMALL>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
+        else if (stamped)
+            hipExtLaunchKernelGGL((k_tree<true, TREE_WAVES_LARGE>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
+        else if (small)
+            hipExtLaunchKernelGGL((k_tree<false, TREE_WAVES_SMALL>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
         else
-            hipExtLaunchKernelGGL((k_tree<false, TREE_WAVES_LARGE, true>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two, rd, wr);
-        if (mode & 2)
-            e->order_parity = wr;
+            hipExtLaunchKernelGGL((k_tree<false, TREE_WAVES_LARGE>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
     };
     launch_tree(false, 2, e->ev_sel);  // select + leaf list
     // queued re-roots run on the side stream, under the tower that follows; the next tree launch waits for them
