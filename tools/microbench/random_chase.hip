@@ -12,14 +12,14 @@
 
 // one record = 1 KiB (64 x 16 B): a node's child list; a region = `region_records` consecutive records (a game's arena)
 __global__ __launch_bounds__(256) void k_chase(const uint4 *__restrict__ buf, unsigned long long n_regions, unsigned region_records,
-                                              int steps, int lanes, int waves_total, unsigned *sink)
+                                              int steps, int lanes, int waves_total, unsigned seed, unsigned *sink)
 {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= waves_total)
         return;
     // every chain stays inside its own region, like a game inside its arena (regions are spread over the whole buffer)
     const unsigned long long region = ((unsigned long long)wave * 2654435761ull) % n_regions;
-    unsigned rec = (unsigned)wave * 40503u % region_records;
+    unsigned rec = ((unsigned)wave * 40503u + seed * 977u) % region_records;
     unsigned acc = 0;
     for (int s = 0; s < steps; s++) {
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -27,7 +27,10 @@ __global__ __launch_bounds__(256) void k_chase(const uint4 *__restrict__ buf, un
             v = buf[(region * region_records + rec) * 64ull + lane];
         // a little arithmetic on what was read, then the next position from it (lane 0's word, like the chosen child's id)
         acc += v.x ^ (v.y >> 3) ^ v.w;
-        const unsigned nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)(v.x + v.z));
+        // (the step number and the launch's seed go into the hash: a pure function of the record read would be a random
+        // map on 612 elements, whose chains fall into cycles of ~25 records within ~30 steps and then live in the caches)
+        unsigned nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)(v.x + v.z)) + (unsigned)s * 0x9E3779B9u + seed * 0x85EBCA6Bu;
+        nxt ^= nxt >> 15; nxt *= 0x2C1B3C6Du; nxt ^= nxt >> 12;
         rec = nxt % region_records;
     }
     if (acc == 0xDEADBEEFu)
@@ -70,7 +73,7 @@ int main(int argc, char **argv)
             for (int rep = 0; rep < 4; rep++) {
                 CK(hipEventRecord(e0, 0));
                 hipLaunchKernelGGL(k_chase, dim3((waves + 3) / 4), dim3(256), 0, 0, (const uint4 *)buf, n_regions, region_records, steps,
-                                   lanes, waves, sink);
+                                   lanes, waves, (unsigned)(rep * 7 + lanes), sink);
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms;
