@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0
+SCATTERED_PEAK_GBS = 5300.0   # dependent scattered 672-B reads, >= 8192 chains in flight, measured (profiles/round3_random_chase.txt)
 ITERS_PER_STEP = 250
 TIMING_STRIDE = 8        # every 8th iteration is event-timed (an event is a barrier packet in the queue)
 PMC_SUMMARY = os.path.join("profiles", "round3_bench_pmc_k_tower.txt")
@@ -359,6 +360,12 @@ def main():
                                          "workgroup, two beyond 8192 games) on the engine's stream; k_advance_list (re-roots) on a high-priority side "
                                          "stream under the tower",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS,
+                              # what this chip delivers for the launch's own access pattern — dependent scattered 672-byte
+                              # reads, one chain per wave (tools/microbench/random_chase.hip): 3.1 TB/s with 4096 chains in
+                              # flight, 5.3 TB/s from 8192 on; `peak` stays the guide's streaming figure
+                              "scattered_read_roofline": {"value": SCATTERED_PEAK_GBS, "unit": "GB/s", "at_chains_in_flight": ">= 8192",
+                                                          "frac": tree_gbs / SCATTERED_PEAK_GBS,
+                                                          "source": "profiles/round3_random_chase.txt"},
                               "tree_phase_ms_per_iteration": tree_ms,
                               "bytes_per_step": tree_bytes(d) / float(max(d["steps"], 1)),
                               "levels_per_step": d["levels"] / float(max(d["steps"], 1)),
