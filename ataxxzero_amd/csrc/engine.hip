@@ -362,6 +362,13 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
         // edge range of the node being scanned, in the packed form the edges carry for their children
         u32 kid = pack_kid(rinfo.x, rinfo.y & 0xFFFFu, (rinfo.y >> 16) != 0u);
         int levels_done = 0;
+        // N of the node being scanned (the sum of its children's visits) without a wave reduction on the level's critical
+        // path: for the root it is the game's root_visits; below, every visit of the edge into a node but the first —
+        // the one that created the node — went on into one of its children, so N = that edge's visits - 1 (the
+        // bookkeeping identity tests/test_gpu_engine.py checks at full size).  A resumed descent does not have the edge it
+        // came through at hand and sums once.
+        bool have_n = !resume;
+        u32 n_node = (u32)s.root_visits;
         for (;;) {
             if (P.select_budget != 0 && levels_done == P.select_budget) {
                 kind = AZH_LEAF_DESCENT;  // park: no leaf for the evaluator from this game this iteration
@@ -389,7 +396,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 if (live)
                     e1 = A.ed[first + lane];
                 const u32 n = edge_visits(e1);
-                const u32 ntot1 = wave_sum_u32(n);
+                const u32 ntot1 = have_n ? n_node : wave_sum_u32(n);
                 const float sq1 = sqrtf((float)(1u + ntot1));
                 const float prior = u2f(e1.x);
                 const float W = u2f(e1.y);
@@ -407,10 +414,13 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 if (lane == 0)
                     path[depth] = (int)eidx;
                 depth++;
-                const u32 child = edge_child(make_uint4(0u, 0u, (u32)read_lane((int)e1.z, bj), 0u));
+                const u32 zsel = (u32)read_lane((int)e1.z, bj);  // the chosen edge: visits | child << 16
+                const u32 child = zsel >> 16;
                 if (child != ENONE) {
                     node = child;
                     kid = (u32)read_lane((int)e1.w, bj);
+                    n_node = (zsel & 0xFFFFu) - 1u;
+                    have_n = true;
                     continue;
                 }
                 // fall through to the expansion below with the general path's variable
@@ -428,7 +438,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                     nsum += edge_visits(ev[k]);
                 }
             }
-            const u32 ntot = wave_sum_u32(nsum);
+            const u32 ntot = have_n ? n_node : wave_sum_u32(nsum);
             const float sq = sqrtf((float)(1u + ntot));
             // arg-max with ties to the LAST maximal edge (:354) — or the FIRST, python's max()
             // (engine.py:291), in the arena: scores are >= 0, so their bit patterns order like
@@ -464,10 +474,13 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             if (lane == 0)
                 path[depth] = (int)eidx;
             depth++;
-            const u32 child = (u32)read_lane((int)mine, bj & 63) >> 16;
+            const u32 zsel = (u32)read_lane((int)mine, bj & 63);
+            const u32 child = zsel >> 16;
             if (child != ENONE) {
                 node = child;
                 kid = (u32)read_lane((int)mkid, bj & 63);
+                n_node = (zsel & 0xFFFFu) - 1u;
+                have_n = true;
                 continue;
             }
             sel_eidx = eidx;
