@@ -60,6 +60,7 @@ constexpr int TREE_WAVES_SMALL = AZH_TREE_WAVES, TREE_WAVES_LARGE = AZH_TREE_WAV
 constexpr int TREE_WAVES_SMALL = 4, TREE_WAVES_LARGE = 2;
 #endif
 constexpr int TREE_ONE_ROUND_GAMES = 8192;  // 8 waves x 4 SIMDs x 256 CUs
+constexpr int TICKET_SHARDS = 64, TICKET_STRIDE = 32;
 // stamps of the diagnostic k_tree<true> (azh_engine_tree_stamps): wave start, state loaded, backup done, mark done,
 // descent done (leaf edge chosen / parked / terminal), expansion done, state stored, workgroup done (all four games)
 constexpr int TREE_STAMPS = 10;  // + [8] levels descended, [9] children scanned in this launch
@@ -95,7 +96,9 @@ struct EngineParams {
     int *leaf_count;
     int *leaf_list2;   // arena: leaves of the games whose mover is net B
     int *leaf_count2;
-    int *tree_done;    // tickets of the workgroups of a k_tree launch (the last one compacts the leaf list)
+    int *tree_done;    // tickets of the workgroups of a k_tree launch (the last one compacts the leaf list): TICKET_SHARDS
+                       // counters, TICKET_STRIDE ints apart, and one on top of them (a single word takes ~88 atomics per
+                       // microsecond: thousands of workgroups finishing together would queue on it)
     u32 *need_mask;    // [2][mask_words] one bit per game: its leaf goes to the net (row 1: to net B, arena); set by
     int mask_words;    // k_tree's workgroups with one atomic OR each, read and cleared by the workgroup that finishes last
     u64 *stamps;       // diagnostic instantiation of k_tree only: [G][TREE_STAMPS] s_memrealtime readings (100 MHz)
@@ -1234,7 +1237,7 @@ __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt
         *P.leaf_count = t1;
         if (two)
             *P.leaf_count2 = t2;
-        __hip_atomic_store(P.tree_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&P.tree_done[TICKET_SHARDS * TICKET_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1306,7 +1309,17 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
                                           __HIP_MEMORY_SCOPE_AGENT);
         // the ORs have returned, i.e. have been performed, before the ticket is drawn
         asm volatile("s_waitcnt vmcnt(0)" : : "v"(seen) : "memory");
-        s_last = __hip_atomic_fetch_add(P.tree_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        // two-level ticket: the workgroup that completes its shard draws a ticket of the top counter
+        const int shard = (int)(blockIdx.x % TICKET_SHARDS);
+        const int in_shard = ((int)gridDim.x - 1 - shard) / TICKET_SHARDS + 1;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&P.tree_done[shard * TICKET_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            __hip_atomic_store(&P.tree_done[shard * TICKET_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int shards = min((int)gridDim.x, TICKET_SHARDS);
+            last = __hip_atomic_fetch_add(&P.tree_done[TICKET_SHARDS * TICKET_STRIDE], 1, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
+        }
+        s_last = last;
     }
     __syncthreads();
     if (s_last)
@@ -1463,7 +1476,7 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.leaf_count, 1);
     rc |= dev_alloc(e, &P.leaf_list2, G);
     rc |= dev_alloc(e, &P.leaf_count2, 1);
-    rc |= dev_alloc(e, &P.tree_done, 1);
+    rc |= dev_alloc(e, &P.tree_done, (size_t)TICKET_SHARDS * TICKET_STRIDE + 1);
     P.mask_words = (P.G + 31) / 32;
     rc |= dev_alloc(e, &P.need_mask, 2 * (size_t)P.mask_words);
     rc |= dev_alloc(e, &P.logits, G * AZH_POLICY_SIZE);
