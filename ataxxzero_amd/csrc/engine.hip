@@ -50,14 +50,15 @@ constexpr u32 RING_MAGIC = 0x415A4847u;  // "AZHG"
 constexpr int NSTAT = AZH_STAT_COUNT;
 constexpr int BFS_QL = 384;  // re-root frontier entries kept in LDS; later ones spill to bfs_spill in HBM
 // Games (one wave each) per workgroup of the fused tree kernel.  Up to 8192 games every game wave is resident at once (8
-// waves per SIMD) and the number hardly matters (tree phase 0.084-0.086 ms for 2 / 4 / 8 / 16 at 4096 games; 0.092 for 1: one
-// ticket and one atomic OR per game); beyond that the waves come in rounds, and a workgroup gives its slots back only when
-// its slowest game is done: at 16384 games 0.203 ms with 2 per workgroup, 0.222 with 4, 0.233 with 8, 0.311 with 16, 0.253
-// with 1 (tools/tree_waves_sweep.sh, profiles/round3_tree_waves_sweep.txt).  -DAZH_TREE_WAVES=n forces one value.
+// waves per SIMD) and the number hardly matters (tree phase 0.084-0.086 ms for 1 / 2 / 4 at 4096 games); beyond that the
+// waves come in rounds, and a workgroup gives its slots back only when its slowest game is done: at 16384 games 0.183 ms
+// with one game per workgroup, 0.203 with 2, 0.222 with 4, 0.233 with 8, 0.311 with 16 (tools/tree_waves_sweep.sh,
+// profiles/round3_tree_waves_sweep.txt; one game per workgroup needs the sharded tickets below: with a single ticket word
+// it was the slowest at 0.253).  -DAZH_TREE_WAVES=n forces one value.
 #ifdef AZH_TREE_WAVES
 constexpr int TREE_WAVES_SMALL = AZH_TREE_WAVES, TREE_WAVES_LARGE = AZH_TREE_WAVES;
 #else
-constexpr int TREE_WAVES_SMALL = 4, TREE_WAVES_LARGE = 2;
+constexpr int TREE_WAVES_SMALL = 4, TREE_WAVES_LARGE = 1;
 #endif
 constexpr int TREE_ONE_ROUND_GAMES = 8192;  // 8 waves x 4 SIMDs x 256 CUs
 constexpr int TICKET_SHARDS = 64, TICKET_STRIDE = 32;

@@ -239,7 +239,7 @@ int azh_engine_stats(azh_engine *e, uint64_t *out /* [AZH_STAT_COUNT] */);
  * next tower start); at most 8192 samples are kept */
 /* Diagnostic: runs two iterations of the device loop with the tree launch between their towers stamped by
  * s_memrealtime (100 MHz): out [games][10] u64 = wave start, state loaded, backup done, move-due mark done, descent done,
- * expansion done, state stored, workgroup (its four games, two beyond 8192) done, then two counts: levels descended, children scanned —
+ * expansion done, state stored, workgroup (its four games, one beyond 8192) done, then two counts: levels descended, children scanned —
  * tools/tree_stamps.py turns them into a breakdown. */
 int azh_engine_tree_stamps(azh_engine *e, azh_net *net, int dtype, uint64_t *out);
 int azh_engine_timing_reset(azh_engine *e, int enable);

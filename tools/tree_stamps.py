@@ -3,7 +3,7 @@
 
 The engine is put in bench.py's steady state (positions of profiles/round2_steady_state_positions.npz, trees grown),
 then `--samples` stamped launches are taken, a few ordinary iterations apart.  Per game wave the stamps are: wave start,
-state loaded, backup done, move-due mark done, descent done, expansion done, state stored, workgroup (its four games; two
+state loaded, backup done, move-due mark done, descent done, expansion done, state stored, workgroup (its four games; one
 beyond 8192 games) done.
 Printed: per phase the mean / median / p90 / max over all waves in microseconds, the start skew of the waves (dispatch),
 and the span of the whole launch (first wave start to last workgroup done), i.e. what the iteration waits for.
