@@ -303,12 +303,21 @@ __global__ __launch_bounds__(WAVE) void k_init_positions(EngineParams P, const u
         P.gs[g] = s;
 }
 
-// azh_engine_set_game_limit before the first iteration: the slots whose first game is already past the limit go idle
-__global__ void k_idle_slots(EngineParams P)
+// azh_engine_set_game_limit: a slot whose game is past the limit and has not begun goes idle; an idle slot whose game
+// is below a (raised) limit starts it
+__global__ __launch_bounds__(WAVE) void k_limit_slots(EngineParams P)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < P.G && P.gs[g].uid >= P.uid_limit)
-        P.gs[g].phase = 3;
+    __shared__ u16 s_moves[MAX_MOVES];
+    const int g = blockIdx.x;
+    azh_game_state s = P.gs[g];
+    if (s.phase == 3 && s.uid < P.uid_limit) {
+        init_game(P, g, s.uid, s, s_moves);
+        if (threadIdx.x == 0)
+            P.gs[g] = s;
+    } else if (s.phase == 0 && s.ply == 0 && s.n_nodes == 1 && s.root_visits == 0 && s.uid >= P.uid_limit) {
+        if (threadIdx.x == 0)
+            P.gs[g].phase = 3;
+    }
 }
 
 __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
@@ -1808,14 +1817,17 @@ extern "C" int azh_engine_set_visits(azh_engine *e, int visits)
 // At most `games` games are played: uids 0 .. games - 1 (slot g plays uids g, g + G, ...).  A slot whose next game
 // would be past the limit goes idle, so the batch thins out as the last games end and no search is spent on games
 // nobody asked for — what a generator given a target count (accelerated_generate_games.py --game-count) wants in
-// uid order, where line N only appears once the slowest of the first N games has ended.  Call before the first iteration.
+// uid order, where line N only appears once the slowest of the first N games has ended.  The limit may be RAISED later
+// (games that were dropped leave the caller short of lines): idle slots whose next game is now below it start it.
+// Games that have begun are never stopped.
 extern "C" int azh_engine_set_game_limit(azh_engine *e, int64_t games)
 {
     if (!e || games < 1 || games > 0xFFFFFFFFll)
         return azh_fail(-1, "azh_engine_set_game_limit: bad argument");
     AZH_HIP(hipStreamSynchronize(e->stream));
+    AZH_HIP(hipStreamSynchronize(e->stream2));
     e->P.uid_limit = (u32)games;
-    hipLaunchKernelGGL(k_idle_slots, dim3((e->P.G + 255) / 256), dim3(256), 0, e->stream, e->P);
+    hipLaunchKernelGGL(k_limit_slots, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
     AZH_HIP(hipGetLastError());
     AZH_HIP(hipStreamSynchronize(e->stream));
     return 0;

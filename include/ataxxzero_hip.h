@@ -260,8 +260,9 @@ int azh_engine_set_emit_order(azh_engine *e, int by_uid);
 /* Play at most `games` games (uids 0 .. games - 1) and then stop searching: a slot whose next game would be past the
  * limit goes idle, the batch thins out as the last games end.  For a generator that was given a target count: in uid
  * order line N appears once the slowest of the first N games has ended, and without a limit every other slot meanwhile
- * plays games nobody will read.  Call before the first iteration.  (The reference's client has no such notion: it is
- * stopped from outside, looper.py:51-64.) */
+ * plays games nobody will read.  The limit may be raised later (dropped games leave the caller short of lines): idle
+ * slots whose next game is now below it start it; games that have begun are never stopped.  (The reference's client has
+ * no such notion: it is stopped from outside, looper.py:51-64.) */
 int azh_engine_set_game_limit(azh_engine *e, int64_t games);
 
 /* ------------------------------------------------------------------ reference ABI

@@ -244,9 +244,13 @@ void orc_engine_set_visits(orc_engine *e, int visits) { e->cfg.visits = visits; 
 void orc_engine_set_game_limit(orc_engine *e, int64_t games)
 {
     e->uid_limit = (uint32_t)games;
-    for (int g = 0; g < e->G; g++)
-        if (e->gs[g].uid >= e->uid_limit)
-            e->gs[g].phase = ORC_PHASE_IDLE;
+    for (int g = 0; g < e->G; g++) {
+        orc_game_state *s = &e->gs[g];
+        if (s->phase == ORC_PHASE_IDLE && s->uid < e->uid_limit)
+            init_game(e, g, s->uid);   /* the limit was raised: the slot plays the game it was waiting with */
+        else if (s->phase == ORC_PHASE_ROOT_EVAL && s->ply == 0 && s->n_nodes == 1 && s->root_visits == 0 && s->uid >= e->uid_limit)
+            s->phase = ORC_PHASE_IDLE; /* a game that has not begun */
+    }
 }
 /* mirror of azh_engine_set_positions: every slot restarts at boards[g] (x | turn << 63, o) / plies[g], fresh tree, uid = g */
 void orc_engine_set_positions(orc_engine *e, const uint64_t *boards, const int32_t *plies)

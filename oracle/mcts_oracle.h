@@ -87,7 +87,7 @@ int orc_engine_edge_cap(const orc_engine *e);
 /* root-visit threshold for the coming moves, 1 .. the value the engine was created with (the arenas are sized for
  * that); mirror of azh_engine_set_visits */
 void orc_engine_set_visits(orc_engine *e, int visits);
-/* mirror of azh_engine_set_game_limit (call before the first iteration) */
+/* mirror of azh_engine_set_game_limit (may be raised later: idle slots below the new limit start their game) */
 void orc_engine_set_game_limit(orc_engine *e, int64_t games);
 /* mirror of azh_engine_set_positions: every slot restarts at boards[g] (x | turn << 63, o) / plies[g] with a fresh tree;
  * such games are counted, not written */

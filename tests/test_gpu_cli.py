@@ -302,20 +302,23 @@ def test_accelerated_generate_games_extension_flags(tmp_path):
 
 
 def test_generator_with_a_game_count_writes_exactly_those_games_and_exits(tmp_path):
-    """--game-count N (extension): the games with uid below N, in uid order, then a clean exit by itself."""
+    """--game-count N (extension; here through $AZH_GAME_COUNT, the way it reaches a generator that looper.py starts): N
+    games in uid order, then a clean exit by itself."""
     conv, bn = model.random_init(1, 128, seed=5)
     net_path = str(tmp_path / "model-003.npy")
     model.save_model(net_path, conv, bn)
     games_path = str(tmp_path / "model-003-0.json")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "accelerated_generate_games.py"), "--network", net_path,
-                          "--output-games", games_path, "--visits", "6", "--buffer-size", "64", "--game-count", "70",
-                          "--seed", "9", "--max-seconds", "120"], cwd=ROOT, capture_output=True, timeout=400)
+                          "--output-games", games_path, "--visits", "6", "--buffer-size", "64",
+                          "--seed", "9", "--max-seconds", "120"], cwd=ROOT, capture_output=True, timeout=400,
+                         env=dict(os.environ, AZH_GAME_COUNT="70"))
     text = res.stdout.decode()
     assert res.returncode == 0, text[-2000:] + res.stderr.decode()[-2000:]
     totals = json.loads(next(l for l in text.splitlines() if l.startswith("Totals: "))[len("Totals: "):])
     lines = [l for l in open(games_path) if l.strip()]
-    assert totals["games_in_flight"] == 70 and totals["written"] == len(lines) == totals["games"]
-    assert totals["games"] + totals["dropped"] == 70 and totals["seconds"] < 100
+    # 70 games WRITTEN: a game cut at 400 plies is made up for by one more (the limit is raised by what is missing)
+    assert totals["games_in_flight"] == 70 and totals["written"] == len(lines) == totals["games"] == 70
+    assert totals["seconds"] < 100
     for line in lines[:10]:
         entry = json.loads(line)
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]

@@ -167,6 +167,16 @@ def test_game_limit_matches_oracle_in_lockstep():
         assert so[k] == sg[k], (k, so[k], sg[k])
     assert so["games"] + so["dropped"] == 30 and so["dropped"] > 0 and len(g_lines) == len(o_games) == so["games"]
     assert all(ge.game_state(g).phase == 3 for g in range(12))
+    # the limit is raised by what the drops left missing: the idle slots start those games, in both engines alike
+    more = so["dropped"]
+    oe.set_game_limit(30 + more)
+    ge.set_game_limit(30 + more)
+    assert sorted(ge.game_state(g).uid for g in range(12) if ge.game_state(g).phase != 3) == list(range(30, 30 + more))[:12]
+    o2, g2 = run_lockstep(oe, ge, 2500, check_every=41)
+    so, sg = oe.stats(), ge.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    assert so["games"] + so["dropped"] == 30 + more and len(g2) == len(o2) and all(ge.game_state(g).phase == 3 for g in range(12))
 
 
 def test_reroot_queue_spill_path_matches_oracle():
