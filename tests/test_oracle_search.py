@@ -230,3 +230,15 @@ def test_game_limit_plays_exactly_the_games_below_it():
     lg, v = synthetic_evals(e.leaf_boards())
     e.backup(lg, v)
     assert e.stats() == st
+    # raising the limit wakes the idle slots whose next game is now below it
+    e.set_game_limit(23)
+    awake = sorted(e.game_state(g).uid for g in range(8) if e.game_state(g).phase != 3)
+    assert awake == [20, 21, 22]
+    for _ in range(4000):
+        e.select()
+        lg, v = synthetic_evals(e.leaf_boards())
+        e.backup(lg, v)
+        st = e.stats()
+        if st["games"] + st["dropped"] >= 23:
+            break
+    assert st["games"] + st["dropped"] == 23 and all(e.game_state(g).phase == 3 for g in range(8))
