@@ -177,6 +177,21 @@ _ARRAYS = {}
 _ARRAYS_MAX = 100000      # entries; about 15 KB each (int8 cells, int16 indices, float32 weights)
 
 
+_FLAT_INDEX = {}          # move as the entry spells it (UAI text, or json's nested lists as tuples) -> flat policy index
+
+
+def _flat_policy_index(mv):
+    """Flat index 119 x + 17 y + layer of a move's cell in the policy heat map, through add_move_to_heatmap itself, once per
+    distinct move (there are 529): a games file names the same few hundred moves millions of times."""
+    key = mv if isinstance(mv, str) else (mv[0] if mv[0] == "c" else tuple(mv[0]), tuple(mv[1]))
+    flat = _FLAT_INDEX.get(key)
+    if flat is None:
+        probe = np.zeros((BOARD, BOARD, MOVE_TYPES))
+        add_move_to_heatmap(probe, uai_decode_move(key) if isinstance(key, str) else key)
+        flat = _FLAT_INDEX[key] = int(np.flatnonzero(probe.ravel())[0])
+    return flat
+
+
 def _entry_arrays(entry):
     """Per-entry arrays for the batched pipeline, built on first use: cells [plies][49] and, per ply, the flat policy
     indices and weights of its target (the visit distribution, or the move played)."""
@@ -184,7 +199,6 @@ def _entry_arrays(entry):
     cache = row[1] if row is not None and row[0] is entry else None
     if cache is None:
         cells = np.asarray(entry["boards"], dtype=np.int8)
-        probe = np.zeros((BOARD, BOARD, MOVE_TYPES))
         idx, wts, start = [], [], [0]
         for ply in range(len(entry["boards"])):
             if "dists" in entry:
@@ -194,13 +208,7 @@ def _entry_arrays(entry):
             for mv, w in items:
                 if mv == "pass":
                     continue
-                if isinstance(mv, str):
-                    mv = uai_decode_move(mv)
-                else:
-                    mv = (mv[0] if mv[0] == "c" else tuple(mv[0]), tuple(mv[1]))
-                probe[...] = 0
-                add_move_to_heatmap(probe, mv)
-                idx.append(int(np.flatnonzero(probe.ravel())[0]))
+                idx.append(_flat_policy_index(mv))
                 wts.append(w)
             start.append(len(idx))
         cache = (cells, np.asarray(idx, dtype=np.int16), np.asarray(wts, dtype=np.float32),
