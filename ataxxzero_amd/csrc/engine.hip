@@ -314,7 +314,8 @@ __global__ __launch_bounds__(WAVE) void k_limit_slots(EngineParams P)
         init_game(P, g, s.uid, s, s_moves);
         if (threadIdx.x == 0)
             P.gs[g] = s;
-    } else if (s.phase == 0 && s.ply == 0 && s.n_nodes == 1 && s.root_visits == 0 && s.uid >= P.uid_limit) {
+    } else if (s.phase == 0 && s.leaf_kind == AZH_LEAF_NONE && s.ply == 0 && s.n_nodes == 1 && s.root_visits == 0 &&
+               s.uid >= P.uid_limit) {  // a game that has not begun (and has no root evaluation in flight)
         if (threadIdx.x == 0)
             P.gs[g].phase = 3;
     }

@@ -248,7 +248,8 @@ void orc_engine_set_game_limit(orc_engine *e, int64_t games)
         orc_game_state *s = &e->gs[g];
         if (s->phase == ORC_PHASE_IDLE && s->uid < e->uid_limit)
             init_game(e, g, s->uid);   /* the limit was raised: the slot plays the game it was waiting with */
-        else if (s->phase == ORC_PHASE_ROOT_EVAL && s->ply == 0 && s->n_nodes == 1 && s->root_visits == 0 && s->uid >= e->uid_limit)
+        else if (s->phase == ORC_PHASE_ROOT_EVAL && s->leaf_kind == ORC_LEAF_NONE && s->ply == 0 && s->n_nodes == 1 &&
+                 s->root_visits == 0 && s->uid >= e->uid_limit)
             s->phase = ORC_PHASE_IDLE; /* a game that has not begun */
     }
 }
