@@ -175,6 +175,9 @@ def main():
     ap.add_argument("--precision-positions", type=int, default=0,
                     help="> 0: finish with tools/precision_in_the_loop.py on the last net (bf16 / f16 search against the f32 "
                          "search on that many positions)")
+    ap.add_argument("--generation-deadline", type=float, default=0.0,
+                    help="> 0: start no further generation after this many seconds (a GPU box call is bounded); the matches "
+                         "and checks then cover the generations that were completed")
     ap.add_argument("--generator-flags", type=str, default="--buffer-size 1024",
                     help="extension flags appended to the generator command (one string)")
     args = ap.parse_args()
@@ -191,7 +194,12 @@ def main():
         model.save_model(model_path(args.prefix, 1), conv, bn)
         log(out, "model-001: random init (model.py:103-114 distributions), seed %d" % args.seed)
 
+    t_start = time.time()
     for n in range(1, args.iterations + 1):
+        if args.generation_deadline > 0 and time.time() - t_start > args.generation_deadline:
+            log(out, "deadline of %.0f s passed after %d generations: going on to the matches" % (args.generation_deadline, n - 1))
+            args.iterations = n - 1
+            break
         if not os.path.exists(model_path(args.prefix, n + 1)):
             g = generate(args, n, out)
             if g is not None:
