@@ -44,8 +44,11 @@ def lane_tile(t):
         assert out[res[cl]] is None
         out[res[cl]]=cl
     return out
-T=[lane_tile(tiles['top']), lane_tile(tiles['bot']), rt[0], rt[1], rt[2],
-   lane_tile(tiles['left']), lane_tile(tiles['right']), rt[3], rt[4], rt[5]]
+# the partial tile (the 10th cell of residues 0, 1, 2: cells 144-146, all on y = 6) goes to wave half 0, whose unrolled
+# inner index is dy: its dy = +1 taps are dropped at compile time like those of the y = 6 edge tile
+assert all(cl is None or cl[2]==6 for cl in rt[5])
+T=[lane_tile(tiles['top']), lane_tile(tiles['bot']), rt[0], rt[1], rt[5],
+   lane_tile(tiles['left']), lane_tile(tiles['right']), rt[2], rt[3], rt[4]]
 seen=set()
 rows=[]
 for t in T:
@@ -59,6 +62,7 @@ assert len(seen)==147
 # checks: skip properties
 for r,cl in enumerate(T[0]): assert cl is None or cl[2]==0
 for r,cl in enumerate(T[1]): assert cl is None or cl[2]==6
+for r,cl in enumerate(T[4]): assert cl is None or cl[2]==6
 for r,cl in enumerate(T[5]): assert cl is None or cl[1]==0
 for r,cl in enumerate(T[6]): assert cl is None or cl[1]==6
 print("static constexpr unsigned short TILE_CELL[10][16] = {")
