@@ -631,21 +631,23 @@ struct Geo2 {
 // as the 16 lanes of a tile keep distinct slots mod 16 (the bank rule of ds_read_b128's 16-lane groups): lane r of a
 // tile always holds a cell with c % 16 == r.  Four tiles are filled with cells of one board edge each — y = 0, y = 6
 // (wave half 0) and x = 0, x = 6 (wave half 1), 16 cells apiece — so the three taps that look past that edge are
-// all-zero for the whole tile and are dropped at compile time (B loads and MFMAs): 12 of the 90 (tile, tap) pairs per
-// layer, 6 per wave half.  The other six tiles take the k-th remaining cell of every residue class.  Generated by
-// tools/tower_tile_table.py; entries >= 0x100 are empty lanes (pseudo cell = lane, never valid).
+// all-zero for the whole tile and are dropped at compile time (B loads and MFMAs).  The other six tiles take the k-th
+// remaining cell of every residue class; the sixth of them holds only the three cells that are left (144-146, all on
+// y = 6) and sits in wave half 0, whose unrolled inner index is dy, so its dy = +1 taps are dropped as well: 15 of the
+// 90 (tile, tap) pairs per layer, 9 in wave half 0 and 6 in wave half 1.  Generated by tools/tower_tile_table.py;
+// entries >= 0x100 are empty lanes (pseudo cell = lane, never valid).
 // The FLOP count reported for the kernel stays the padded-tap figure.
 __device__ const unsigned short TILE_CELL[10][16] = {
     {0x010, 0x001, 0x002, 0x003, 0x004, 0x005, 0x006, 0x007, 0x008, 0x009, 0x00a, 0x00b, 0x00c, 0x00d, 0x00e, 0x00f},
     {0x080, 0x081, 0x082, 0x083, 0x084, 0x085, 0x086, 0x087, 0x088, 0x089, 0x08a, 0x08b, 0x08c, 0x08d, 0x08e, 0x07f},
     {0x000, 0x011, 0x012, 0x013, 0x024, 0x025, 0x016, 0x017, 0x018, 0x019, 0x01a, 0x02b, 0x02c, 0x01d, 0x01e, 0x01f},
     {0x020, 0x021, 0x032, 0x033, 0x034, 0x035, 0x026, 0x027, 0x028, 0x039, 0x03a, 0x03b, 0x03c, 0x02d, 0x02e, 0x02f},
-    {0x040, 0x041, 0x042, 0x043, 0x044, 0x055, 0x036, 0x047, 0x048, 0x049, 0x04a, 0x04b, 0x05c, 0x03d, 0x04e, 0x04f},
+    {0x090, 0x091, 0x092, 0x103, 0x104, 0x105, 0x106, 0x107, 0x108, 0x109, 0x10a, 0x10b, 0x10c, 0x10d, 0x10e, 0x10f},
     {0x070, 0x031, 0x062, 0x023, 0x054, 0x015, 0x046, 0x077, 0x038, 0x069, 0x02a, 0x05b, 0x01c, 0x04d, 0x07e, 0x03f},
     {0x030, 0x061, 0x022, 0x053, 0x014, 0x045, 0x076, 0x037, 0x068, 0x029, 0x05a, 0x01b, 0x04c, 0x07d, 0x03e, 0x06f},
+    {0x040, 0x041, 0x042, 0x043, 0x044, 0x055, 0x036, 0x047, 0x048, 0x049, 0x04a, 0x04b, 0x05c, 0x03d, 0x04e, 0x04f},
     {0x050, 0x051, 0x052, 0x063, 0x064, 0x065, 0x056, 0x057, 0x058, 0x059, 0x06a, 0x06b, 0x06c, 0x05d, 0x05e, 0x05f},
     {0x060, 0x071, 0x072, 0x073, 0x074, 0x075, 0x066, 0x067, 0x078, 0x079, 0x07a, 0x07b, 0x07c, 0x06d, 0x06e, 0x08f},
-    {0x090, 0x091, 0x092, 0x103, 0x104, 0x105, 0x106, 0x107, 0x108, 0x109, 0x10a, 0x10b, 0x10c, 0x10d, 0x10e, 0x10f},
 };
 
 __device__ inline void cell_xy(int c, int &bl, int &x, int &y)
@@ -658,8 +660,12 @@ __device__ inline void cell_xy(int c, int &bl, int &x, int &y)
 
 // The taps of a layer are walked as three rows of three: wave half 0 walks dx in the (run-time) row loop and dy inside
 // the unrolled row, wave half 1 the other way round, so that for both halves "tile 0 skips inner index 0, tile 1 skips
-// inner index 2" is a compile-time fact.
-__device__ constexpr bool skip_pair(int ct, int inner) { return (ct == 0 && inner == 0) || (ct == 1 && inner == 2); }
+// inner index 2" is a compile-time fact; in wave half 0 the partial tile (4) skips inner index 2 like the y = 6 tile.
+// (the partial tile's three pairs: +1.1 % at 3.6 K and 16 K boards, profiles/round3_partial_tile_skip.txt)
+__device__ constexpr bool skip_pair(int chf, int ct, int inner)
+{
+    return (ct == 0 && inner == 0) || (ct == 1 && inner == 2) || (chf == 0 && ct == 4 && inner == 2);
+}
 
 template <int DT, int KS, int CHF, bool STAMP>
 __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, bool skip,
@@ -766,7 +772,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         const int drow = CHF == 0 ? (o - 1) + 21 * (i - 1) : (i - 1) + 21 * (o - 1);
         static_for<0, TPW>([&](auto ct_tag) {
             constexpr int ct = decltype(ct_tag)::value;
-            if constexpr (!skip_pair(ct, i)) {
+            if constexpr (!skip_pair(CHF, ct, i)) {
 #if AZH_OOBZERO
                 // An LDS read past the workgroup's allocation returns zeros (tools/microbench/lds_oob.hip): a tap that
                 // looks off the board sets bit 28 of its byte address instead of being steered to a zero slot — three
@@ -787,7 +793,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
         constexpr int i = decltype(i_tag)::value;
         static_for<0, TPW>([&](auto ct_tag) {
             constexpr int ct = decltype(ct_tag)::value;
-            if constexpr (!skip_pair(ct, i))
+            if constexpr (!skip_pair(CHF, ct, i))
                 bf[ct] = *reinterpret_cast<const afrag *>(lds + rows[ct] + ks * (4 * G::CS));
         });
     };
@@ -826,9 +832,9 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             for (int t = 0; t < 4; t++)
                 static_for<0, TPW>([&](auto ct_tag) {
                     constexpr int ct = decltype(ct_tag)::value;
-                    if constexpr (!skip_pair(ct, i)) {
+                    if constexpr (!skip_pair(CHF, ct, i)) {
                         // the first step this cell tile takes part in (tile 0 sits out inner tap 0)
-                        constexpr bool opens = FIRST && j == (skip_pair(ct, 0) ? KS : 0);
+                        constexpr bool opens = FIRST && j == (skip_pair(CHF, ct, 0) ? KS : 0);
                         acc[t][ct] = Mfma16<DT>::mfma(a[rs][t], b[par][ct], opens ? shq[t] : acc[t][ct]);
                     }
                 });
