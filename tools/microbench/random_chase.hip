@@ -3,7 +3,7 @@
 // position that depends on the data just read (a PUCT level: the next node is only known once this node's children are
 // scored).  Reports, for W chains in flight over a buffer of a few GiB, the time per dependent step and the bytes per
 // second of the whole chip — i.e. what HBM3E and the fabric deliver for THIS access pattern, to put beside the 8 TB/s of
-// streaming reads.  build: hipcc -O3 --offload-arch=gfx950 random_chase.hip -o random_chase ; run: ./random_chase [GiB]
+// streaming reads.  build: hipcc -O3 --offload-arch=gfx950 random_chase.hip -o random_chase ; run: ./random_chase [GiB [reads per step: 1 | 2]]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -11,8 +11,10 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 // one record = 1 KiB (64 x 16 B): a node's child list; a region = `region_records` consecutive records (a game's arena)
+// `reads` = 2: every step issues a second, independent read of the same shape (another record of the chain's region,
+// its position known when the first is issued) — do two requests of a wave in flight cost what one costs?
 __global__ __launch_bounds__(256) void k_chase(const uint4 *__restrict__ buf, unsigned long long n_regions, unsigned region_records,
-                                              int steps, int lanes, int waves_total, unsigned seed, unsigned *sink)
+                                              int steps, int lanes, int waves_total, unsigned seed, unsigned *sink, int reads)
 {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= waves_total)
@@ -22,9 +24,13 @@ __global__ __launch_bounds__(256) void k_chase(const uint4 *__restrict__ buf, un
     unsigned rec = ((unsigned)wave * 40503u + seed * 977u) % region_records;
     unsigned acc = 0;
     for (int s = 0; s < steps; s++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (lane < lanes)
-            v = buf[(region * region_records + rec) * 64ull + lane];
+        // (lanes beyond `lanes` re-read lane 0's 16 bytes: no request of their own, and no branch around the loads — a
+        // load under its own branch is waited for before the branch ends, which would serialise the two reads)
+        const int l = lane < lanes ? lane : 0;
+        const unsigned rec2 = reads == 2 ? (rec * 7u + 13u + (unsigned)s) % region_records : rec;
+        const uint4 v = buf[(region * region_records + rec) * 64ull + l];
+        const uint4 v2 = buf[(region * region_records + rec2) * 64ull + l];
+        acc += v2.x ^ v2.y ^ v2.z ^ v2.w;
         // a little arithmetic on what was read, then the next position from it (lane 0's word, like the chosen child's id)
         acc += v.x ^ (v.y >> 3) ^ v.w;
         // (the step number and the launch's seed go into the hash: a pure function of the record read would be a random
@@ -51,6 +57,7 @@ __global__ void k_fill(uint4 *buf, unsigned long long n)
 int main(int argc, char **argv)
 {
     const double gib = argc > 1 ? atof(argv[1]) : 8.0;
+    const int reads = argc > 2 ? atoi(argv[2]) : 1;
     const unsigned region_records = 612;                    // 612 KiB: one game's edge arena at 400 sims (39,168 edges x 16 B)
     const unsigned long long n_regions = (unsigned long long)(gib * 1024.0 * 1024.0 / region_records);
     const unsigned long long n = n_regions * region_records * 64ull;
@@ -63,8 +70,8 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    printf("dependent scattered reads over %.1f GiB in %llu regions of %u KiB, one chain per wave, 48 steps per chain\n", gib, n_regions,
-           region_records);
+    printf("dependent scattered reads over %.1f GiB in %llu regions of %u KiB, one chain per wave, 48 steps per chain, %d read(s) per step\n",
+           gib, n_regions, region_records, reads);
     printf("%6s %6s %8s | %10s %12s %12s\n", "waves", "lanes", "B/lane", "us/step", "GB/s (req.)", "GB/s (64B sectors)");
     const int steps = 48;
     for (int lanes : {42, 64}) {
@@ -73,7 +80,7 @@ int main(int argc, char **argv)
             for (int rep = 0; rep < 4; rep++) {
                 CK(hipEventRecord(e0, 0));
                 hipLaunchKernelGGL(k_chase, dim3((waves + 3) / 4), dim3(256), 0, 0, (const uint4 *)buf, n_regions, region_records, steps,
-                                   lanes, waves, (unsigned)(rep * 7 + lanes), sink);
+                                   lanes, waves, (unsigned)(rep * 7 + lanes), sink, reads);
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms;
@@ -81,8 +88,8 @@ int main(int argc, char **argv)
                 if (rep > 0 && ms < best)
                     best = ms;
             }
-            const double bytes = (double)waves * steps * lanes * 16.0;
-            const double sectors = (double)waves * steps * ((lanes * 16 + 63) / 64) * 64.0;
+            const double bytes = (double)waves * steps * lanes * 16.0 * reads;
+            const double sectors = (double)waves * steps * ((lanes * 16 + 63) / 64) * 64.0 * reads;
             // a launch of more waves than fit (8192) runs in rounds: us/step is per chain, over the rounds it needs
             const double rounds = waves > 8192 ? waves / 8192.0 : 1.0;
             printf("%6d %6d %8d | %10.3f %12.0f %12.0f\n", waves, lanes, 16, best * 1e3 / steps / rounds, bytes / (best * 1e-3) / 1e9,
