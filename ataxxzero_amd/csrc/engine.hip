@@ -383,6 +383,40 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
         // came through at hand and sums once.
         bool have_n = !resume;
         u32 n_node = (u32)s.root_visits;
+        // The path of the descent: lane k keeps the k-th entry added in this launch and the entries are stored together
+        // afterwards (every 64 levels when there is no budget): a store per level would have to be acknowledged before
+        // the next level's records count as arrived (vmcnt counts stores in order with the loads).
+        u32 path_buf = 0;
+        int path_base = depth;
+        auto push_path = [&](u32 eidx) {
+            if (lane == depth - path_base)
+                path_buf = eidx;
+            depth++;
+            if (depth - path_base == WAVE) {
+                path[path_base + lane] = (int)path_buf;
+                path_base = depth;
+            }
+        };
+        // Early request of the next level (never changes what is selected): a node remembers which child the last descent
+        // through it chose, in the `w` word of its first UNVISITED edge (an edge without a child has no use for the word;
+        // 1 << 31 | index; an expansion that takes that edge simply overwrites it).  When a node's records arrive, the
+        // remembered child's own records — its range is in this node's records — are requested at once and the scores are
+        // computed while they are in flight; if the scores pick that child, the next level starts with its records
+        // already on the way: a level then costs max(memory latency, its instructions) instead of their sum.
+        // (two records per lane: nodes of up to 128 moves take this path — a third of the nodes of a mid-game position have
+        // more than 64)
+        uint4 ea0 = fresh_edge(0u), ea1 = fresh_edge(0u), en0 = fresh_edge(0u), en1 = fresh_edge(0u);
+        bool cur_loaded = false;
+        auto load_children = [&](u32 k, uint4 &r0, uint4 &r1) {
+            const int cnt = kid_count(k);
+            const u32 f = kid_first(k);
+            r0 = fresh_edge(0u);
+            r1 = fresh_edge(0u);
+            if (lane < cnt)
+                r0 = A.ed[f + (u32)lane];
+            if (cnt > WAVE && lane + WAVE < cnt)
+                r1 = A.ed[f + (u32)(lane + WAVE)];
+        };
         for (;;) {
             if (P.select_budget != 0 && levels_done == P.select_budget) {
                 kind = AZH_LEAF_DESCENT;  // park: no leaf for the evaluator from this game this iteration
@@ -401,38 +435,110 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             st_levels += 1;
             st_children += (u64)M;
             u32 sel_eidx = 0;
-            if (M <= WAVE) {
-                // Fast path (nearly every node): one edge per lane.  Same arithmetic as the general path below;
-                // the arg-max is a 32-bit max of the score bits plus a ballot for the tie rule, instead of a
-                // 64-bit (score, index) key reduction — this loop is a latency chain, instructions count.
-                uint4 e1 = fresh_edge(0u);
-                const bool live = lane < M;
-                if (live)
-                    e1 = A.ed[first + lane];
-                const u32 n = edge_visits(e1);
-                const u32 ntot1 = have_n ? n_node : wave_sum_u32(n);
+            if (M <= 2 * WAVE) {
+                // Fast path (all but a handful of nodes): one edge per lane, two beyond 64 moves.  Same arithmetic as the
+                // general path below; the arg-max is a 32-bit max of the score bits plus ballots for the tie rule,
+                // instead of a 64-bit (score, index) key reduction — this loop is a latency chain, instructions count.
+                if (!cur_loaded)
+                    load_children(kid, ea0, ea1);
+                cur_loaded = false;
+                const uint4 e0 = ea0, e1 = ea1;
+                const bool two = M > WAVE;
+                const bool live0 = lane < M, live1 = two && lane + WAVE < M;
+                // the remembered child, requested before anything is scored
+                const u64 unv0 = __ballot(live0 && edge_child(e0) == ENONE);
+                const u64 unv1 = two ? __ballot(live1 && edge_child(e1) == ENONE) : 0ull;
+                int u0 = -1, pv = -1, pred = -1;
+                if (unv0 | unv1) {
+                    u32 hw;
+                    if (unv0) {
+                        u0 = __ffsll((long long)unv0) - 1;
+                        hw = (u32)read_lane((int)e0.w, u0);
+                    } else {
+                        u0 = __ffsll((long long)unv1) - 1;
+                        hw = (u32)read_lane((int)e1.w, u0);
+                        u0 += WAVE;
+                    }
+                    if ((hw >> 31) && (int)(hw & 0xFFu) < M) {
+                        pv = (int)(hw & 0xFFu);
+                        u32 pz, pk;
+                        if (pv < WAVE) {
+                            pz = (u32)read_lane((int)e0.z, pv);
+                            pk = (u32)read_lane((int)e0.w, pv);
+                        } else {
+                            pz = (u32)read_lane((int)e1.z, pv - WAVE);
+                            pk = (u32)read_lane((int)e1.w, pv - WAVE);
+                        }
+                        if ((pz >> 16) != ENONE && !kid_finished(pk) && kid_count(pk) > 0 && kid_count(pk) <= 2 * WAVE) {
+                            load_children(pk, en0, en1);
+                            pred = pv;
+                        }
+                    }
+                }
+                const u32 n0 = edge_visits(e0), n1 = edge_visits(e1);
+                const u32 ntot1 = have_n ? n_node : wave_sum_u32(n0 + n1);
                 const float sq1 = sqrtf((float)(1u + ntot1));
-                const float prior = u2f(e1.x);
-                const float W = u2f(e1.y);
-                const float q = n ? W / (float)n : 0.0f;
-                const float u = (sq1 / (1.0f + (float)n)) * (P.c_puct * prior);
-                const float score = u + q;
-                const bool valid = live && score >= 0.0f;  // NaN scores are never selected by either reference
-                const u32 bits = valid ? f2u(score + 0.0f) : 0u;
-                const u32 top = wave_max_u32(bits);
-                const u64 cand = __ballot(valid && bits == top);
+                u32 bits0, bits1 = 0u;
+                bool valid0, valid1 = false;
+                {
+                    const float prior = u2f(e0.x);
+                    const float W = u2f(e0.y);
+                    const float q = n0 ? W / (float)n0 : 0.0f;
+                    const float u = (sq1 / (1.0f + (float)n0)) * (P.c_puct * prior);
+                    const float score = u + q;
+                    valid0 = live0 && score >= 0.0f;  // NaN scores are never selected by either reference
+                    bits0 = valid0 ? f2u(score + 0.0f) : 0u;
+                }
+                if (two) {
+                    const float prior = u2f(e1.x);
+                    const float W = u2f(e1.y);
+                    const float q = n1 ? W / (float)n1 : 0.0f;
+                    const float u = (sq1 / (1.0f + (float)n1)) * (P.c_puct * prior);
+                    const float score = u + q;
+                    valid1 = live1 && score >= 0.0f;
+                    bits1 = valid1 ? f2u(score + 0.0f) : 0u;
+                }
+                const u32 top = wave_max_u32(bits0 > bits1 ? bits0 : bits1);
+                const u64 cand0 = __ballot(valid0 && bits0 == top);
+                const u64 cand1 = two ? __ballot(valid1 && bits1 == top) : 0ull;
                 int bj = 0;
-                if (cand)
-                    bj = (P.flags & AZH_FLAG_TIE_FIRST) ? (__ffsll((long long)cand) - 1) : (63 - __clzll((long long)cand));
+                if (P.flags & AZH_FLAG_TIE_FIRST) {
+                    if (cand0)
+                        bj = __ffsll((long long)cand0) - 1;
+                    else if (cand1)
+                        bj = WAVE + __ffsll((long long)cand1) - 1;
+                } else {
+                    if (cand1)
+                        bj = WAVE + 63 - __clzll((long long)cand1);
+                    else if (cand0)
+                        bj = 63 - __clzll((long long)cand0);
+                }
                 const u32 eidx = first + (u32)bj;
-                if (lane == 0)
-                    path[depth] = (int)eidx;
-                depth++;
-                const u32 zsel = (u32)read_lane((int)e1.z, bj);  // the chosen edge: visits | child << 16
+                push_path(eidx);
+                // the chosen edge: visits | child << 16, and the child's range
+                u32 zsel, wsel;
+                if (bj < WAVE) {
+                    zsel = (u32)read_lane((int)e0.z, bj);
+                    wsel = (u32)read_lane((int)e0.w, bj);
+                } else {
+                    zsel = (u32)read_lane((int)e1.z, bj - WAVE);
+                    wsel = (u32)read_lane((int)e1.w, bj - WAVE);
+                }
                 const u32 child = zsel >> 16;
                 if (child != ENONE) {
+                    // remember the choice (stored only when it changes)
+                    if (u0 >= 0 && bj != pv && lane == 0)
+                        reinterpret_cast<u32 *>(&A.ed[first + (u32)u0])[3] = 0x80000000u | (u32)bj;
+                    if (pred == bj) {
+                        // (a real branch, not a select: a select would wait for the requested records — and for the store
+                        // above — on the path that does not use them)
+                        asm volatile("; the records requested before the scores were computed" ::);
+                        ea0 = en0;
+                        ea1 = en1;
+                        cur_loaded = true;
+                    }
                     node = child;
-                    kid = (u32)read_lane((int)e1.w, bj);
+                    kid = wsel;
                     n_node = (zsel & 0xFFFFu) - 1u;
                     have_n = true;
                     continue;
@@ -485,9 +591,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             key = wave_max_u64(key);
             const int bj = key ? (int)((u32)key ^ tie_flip) : 0;  // key 0: edge 0 = lane 0's round-0 default
             const u32 eidx = first + (u32)bj;
-            if (lane == 0)
-                path[depth] = (int)eidx;
-            depth++;
+            push_path(eidx);
             const u32 zsel = (u32)read_lane((int)mine, bj & 63);
             const u32 child = zsel >> 16;
             if (child != ENONE) {
@@ -495,6 +599,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 kid = (u32)read_lane((int)mkid, bj & 63);
                 n_node = (zsel & 0xFFFFu) - 1u;
                 have_n = true;
+                cur_loaded = false;
                 continue;
             }
             sel_eidx = eidx;
@@ -565,6 +670,9 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             leaf_opp = cb.turn ? cb.x : cb.o;
             break;
         }
+        // the path entries of this launch, one store for all of them (none after an overflow: depth is 0 then)
+        if (lane < depth - path_base)
+            path[path_base + lane] = (int)path_buf;
     }
 
     s.leaf_kind = kind;
