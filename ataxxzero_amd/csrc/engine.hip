@@ -158,7 +158,9 @@ __device__ inline Arena arena_of(const EngineParams &P, int a, int g)
 // level loads share the memory system (tools/tree_stamps.py: a level costs 0.93 us at 1024 games, 1.37 at 4096).
 //   x  prior (f32 bits)                      y  total score W (f32 bits)
 //   z  visits (bits 0-15) | child node (bits 16-31, ENONE = not expanded)
-//   w  the child's first edge (bits 0-22) | its edge count (bits 23-30) | finished position (bit 31)
+//   w  the child's first edge (bits 0-22) | its edge count (bits 23-30) | finished position (bit 31); in an edge WITHOUT a
+//      child the word is free: the node's first such edge keeps 1 << 31 | index of the child the last descent chose here
+//      (select_game's early request of the next level; never read by anything else, not part of the documented tree)
 // visits <= 60000 and nodes <= visits + 8 (azh_engine_create), edges per game < 2^23, moves per position <= 255.
 constexpr u32 ENONE = 0xFFFFu;
 __device__ inline u32 edge_visits(const uint4 &e) { return e.z & 0xFFFFu; }
