@@ -100,6 +100,7 @@ SIGNATURES = {
     "azh_engine_timing_reset": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_timing": (ctypes.c_int, [_vp, _P(Timing)]),
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
+    "azh_format_record_json": (ctypes.c_int, [_vp, ctypes.c_int64, _i32, _vp, ctypes.c_int64, _P(ctypes.c_int64)]),
     "azh_engine_set_emit_order": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_set_positions": (ctypes.c_int, [_vp, _vp, _vp]),
     "azh_engine_set_game_limit": (ctypes.c_int, [_vp, ctypes.c_int64]),
@@ -170,6 +171,21 @@ def complete_workload(workload, posteriors, values):
 
 def shutdown():
     load().shutdown()
+
+
+def format_record_json(rec, with_ids=False):
+    """The JSON line (bytes, no newline) of one finished-game record — uint32 words as the device loop leaves them in its
+    ring — in the reference's entry format (cpp/self_play_client.cpp:565-578,639-641).  Host code only: no GPU needed."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint32)
+    buf = np.zeros(1 << 16, dtype=np.uint8)
+    used = ctypes.c_int64(0)
+    rc = load().azh_format_record_json(_ptr(rec), rec.size, int(bool(with_ids)), _ptr(buf), buf.nbytes, ctypes.byref(used))
+    if rc == -6:
+        buf = np.zeros(used.value, dtype=np.uint8)
+        rc = load().azh_format_record_json(_ptr(rec), rec.size, int(bool(with_ids)), _ptr(buf), buf.nbytes,
+                                           ctypes.byref(used))
+    check(rc)
+    return bytes(buf[:used.value])
 
 
 # ------------------------------------------------------------------ rules

@@ -250,6 +250,14 @@ int azh_engine_timing(azh_engine *e, azh_timing *out);
  * result; one compact object per line).  Writes whole lines only; *used = bytes
  * written, *n_games = lines written; call again while *n_games > 0. */
 int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, int32_t *n_games);
+/* The line of ONE finished-game record (the words between two ring headers, as the device loop leaves them: 8-word header
+ * {magic, slot, uid, plies, result, words, random_ply + 1, kind}, then per ply {x lo, x hi, o lo, o hi, move | nd << 16, 0,
+ * nd x (move | visits << 16)}) exactly as azh_engine_drain_json writes it, without the newline: what the reference's
+ * `entry.dump()` gives (cpp/self_play_client.cpp:565-578,639-641: nlohmann::json — sorted keys, no whitespace, floats as
+ * shortest round-trip digits, plain decimals from 1e-4 up, d.ddde-XX below).  Host code only, usable without a device.
+ * *used = bytes the line has; -6 if `cap` is smaller (nothing written), -2 if the words are not a well-formed record.
+ * with_ids: the arena's two extra keys (slot, uid). */
+int azh_format_record_json(const uint32_t *rec, int64_t words, int32_t with_ids, char *buf, int64_t cap, int64_t *used);
 /* Order in which azh_engine_drain_json hands games out: 0 (default) as they finish; 1 by game uid (slot g plays
  * uids g, g + games, g + 2 games, ...): a finished game is held back until every game with a smaller uid has been
  * handed out or dropped.  The reference's workers write games as they finish (Worker::thread_main :637-642) and
