@@ -1503,6 +1503,8 @@ struct azh_engine {
     // finished games formatted but not yet handed out
     std::vector<std::string> pending;
     size_t pending_pos = 0;
+    // records taken off the device (azh_engine_fetch) and not yet formatted
+    std::vector<uint32_t> staged;
     // uid-ordered emission: finished games wait here until every game with a smaller uid has been handed out or
     // is known to have been dropped ("" = dropped)
     bool emit_by_uid = false;
@@ -1975,6 +1977,7 @@ extern "C" int azh_engine_set_positions(azh_engine *e, const uint64_t *boards, c
     // for uid order) belongs to uids that are about to be reused, and is discarded with them
     e->pending.clear();
     e->pending_pos = 0;
+    e->staged.clear();
     e->held.clear();
     e->next_uid = 0;
     e->order_broken = false;
@@ -2091,6 +2094,84 @@ extern "C" int azh_engine_timing(azh_engine *e, azh_timing *out)
     return 0;
 }
 
+// Takes the finished-game records off the device: waits for the work enqueued so far, copies the record ring to the host
+// and empties it.  azh_engine_drain_json formats what was fetched without touching the device, so a caller may start its
+// next run between the two calls and the formatting (a quarter of a millisecond per 150-ply game) and its own file
+// writes happen under that run instead of in front of it.  Calling it is optional: a drain with nothing fetched fetches.
+extern "C" int azh_engine_fetch(azh_engine *e)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_fetch: null engine");
+    AZH_HIP(hipStreamSynchronize(e->stream));
+    u64 head = 0;
+    AZH_HIP(hipMemcpy(&head, e->P.ring_head, 8, hipMemcpyDeviceToHost));
+    if (head > e->P.ring_cap_words) {
+        // A record or a drop marker did not fit (AZH_STAT_RING_OVERFLOW counts them): its uid will never come, and
+        // uid order would wait for it for ever.  From here on the order is given up instead of the games: what is
+        // held is handed out, and later games are handed out as they arrive.
+        head = e->P.ring_cap_words;
+        e->order_broken = true;
+    }
+    if (head > 0) {
+        const size_t at = e->staged.size();
+        e->staged.resize(at + (size_t)head);
+        AZH_HIP(hipMemcpy(e->staged.data() + at, e->P.ring, (size_t)head * 4, hipMemcpyDeviceToHost));
+        AZH_HIP(hipMemset(e->P.ring, 0, (size_t)head * 4));
+        AZH_HIP(hipMemset(e->P.ring_head, 0, 8));
+    }
+    return 0;
+}
+
+// the fetched records -> lines (in uid order where that is asked for); host work only
+static void format_staged(azh_engine *e)
+{
+    std::vector<uint32_t> host;
+    host.swap(e->staged);
+    std::vector<std::pair<uint32_t, size_t>> order;  // (uid, offset)
+    size_t pos = 0;
+    // (two fetches may sit behind each other in the staging buffer: a fetch that ended in a record cut off by a full
+    // ring is followed by the next one's first header, which the scan finds again at the next magic word)
+    while (pos + 8 <= host.size()) {
+        if (host[pos] != RING_MAGIC) {
+            pos++;
+            continue;
+        }
+        const size_t words = host[pos + 5];
+        if (words < 8 || pos + words > host.size()) {
+            pos++;
+            continue;
+        }
+        order.emplace_back(host[pos + 2], pos);
+        pos += words;
+    }
+    std::sort(order.begin(), order.end());
+    const bool ids = (e->P.flags & AZH_FLAG_TWO_NETS) != 0;
+    for (auto &o : order) {
+        const uint32_t *rec = host.data() + o.second;
+        const bool dropped = rec[7] == 1;
+        std::string line = dropped ? std::string() : azh_format_game_json(rec, rec[5], ids);
+        if (rec[7] == 2)
+            line.clear();  // a game that began at a loaded position: record drained and formatted like any other
+                           // (the measured path does the same work per finished ply), but it is not a whole game
+        if (e->emit_by_uid && !e->order_broken)
+            e->held[o.first] = std::move(line);
+        else if (!line.empty())
+            e->pending.push_back(std::move(line));
+    }
+    // (belt and braces: the longest possible game, 400 plies, outlives a few generations of short ones in the
+    // other slots — not sixteen)
+    if (e->held.size() > 16 * (size_t)e->P.G + 64)
+        e->order_broken = true;
+    if (e->emit_by_uid) {
+        for (auto it = e->held.begin(); it != e->held.end() && (e->order_broken || it->first == e->next_uid);
+             it = e->held.erase(it)) {
+            if (!it->second.empty())
+                e->pending.push_back(std::move(it->second));
+            e->next_uid = it->first + 1;
+        }
+    }
+}
+
 extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, int32_t *n_games)
 {
     if (!e || !buf || !used || !n_games)
@@ -2100,57 +2181,13 @@ extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int6
     if (e->pending_pos >= e->pending.size()) {
         e->pending.clear();
         e->pending_pos = 0;
-        AZH_HIP(hipStreamSynchronize(e->stream));
-        u64 head = 0;
-        AZH_HIP(hipMemcpy(&head, e->P.ring_head, 8, hipMemcpyDeviceToHost));
-        if (head > e->P.ring_cap_words) {
-            // A record or a drop marker did not fit (AZH_STAT_RING_OVERFLOW counts them): its uid will never come, and
-            // uid order would wait for it for ever.  From here on the order is given up instead of the games: what is
-            // held is handed out, and later games are handed out as they arrive.
-            head = e->P.ring_cap_words;
-            e->order_broken = true;
+        if (e->staged.empty()) {
+            const int rc = azh_engine_fetch(e);
+            if (rc)
+                return rc;
         }
-        if (head > 0) {
-            std::vector<uint32_t> host((size_t)head);
-            AZH_HIP(hipMemcpy(host.data(), e->P.ring, (size_t)head * 4, hipMemcpyDeviceToHost));
-            AZH_HIP(hipMemset(e->P.ring, 0, (size_t)head * 4));
-            AZH_HIP(hipMemset(e->P.ring_head, 0, 8));
-            std::vector<std::pair<uint32_t, size_t>> order;  // (uid, offset)
-            size_t pos = 0;
-            while (pos + 8 <= host.size() && host[pos] == RING_MAGIC) {
-                const size_t words = host[pos + 5];
-                if (words < 8 || pos + words > host.size())
-                    break;
-                order.emplace_back(host[pos + 2], pos);
-                pos += words;
-            }
-            std::sort(order.begin(), order.end());
-            const bool ids = (e->P.flags & AZH_FLAG_TWO_NETS) != 0;
-            for (auto &o : order) {
-                const uint32_t *rec = host.data() + o.second;
-                const bool dropped = rec[7] == 1;
-                std::string line = dropped ? std::string() : azh_format_game_json(rec, rec[5], ids);
-                if (rec[7] == 2)
-                    line.clear();  // a game that began at a loaded position: record drained and formatted like any other
-                                   // (the measured path does the same work per finished game), but it is not a whole game
-                if (e->emit_by_uid && !e->order_broken)
-                    e->held[o.first] = std::move(line);
-                else if (!line.empty())
-                    e->pending.push_back(std::move(line));
-            }
-            // (belt and braces: the longest possible game, 400 plies, outlives a few generations of short ones in the
-            // other slots — not sixteen)
-            if (e->held.size() > 16 * (size_t)e->P.G + 64)
-                e->order_broken = true;
-            if (e->emit_by_uid) {
-                for (auto it = e->held.begin(); it != e->held.end() && (e->order_broken || it->first == e->next_uid);
-                     it = e->held.erase(it)) {
-                    if (!it->second.empty())
-                        e->pending.push_back(std::move(it->second));
-                    e->next_uid = it->first + 1;
-                }
-            }
-        }
+        if (!e->staged.empty())
+            format_staged(e);
     }
     while (e->pending_pos < e->pending.size()) {
         const std::string &line = e->pending[e->pending_pos];

@@ -99,6 +99,7 @@ SIGNATURES = {
     "azh_engine_tree_stamps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
     "azh_engine_timing_reset": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_timing": (ctypes.c_int, [_vp, _P(Timing)]),
+    "azh_engine_fetch": (ctypes.c_int, [_vp]),
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
     "azh_format_record_json": (ctypes.c_int, [_vp, ctypes.c_int64, _i32, _vp, ctypes.c_int64, _P(ctypes.c_int64)]),
     "azh_engine_set_emit_order": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -415,6 +416,11 @@ class Engine:
         t = Timing()
         check(load().azh_engine_timing(self.h, ctypes.byref(t)))
         return {"select_ms": t.select_ms, "net_ms": t.net_ms, "backup_ms": t.backup_ms, "iterations": t.iterations}
+
+    def fetch(self):
+        """Wait for the work enqueued so far and take its finished games off the device; the next drain_json formats
+        them without touching the GPU (so the next run can be enqueued in between)."""
+        check(load().azh_engine_fetch(self.h))
 
     def drain_json(self):
         """Finished games since the last call, as a list of JSON lines (bytes, no newline)."""

@@ -127,6 +127,11 @@ class SelfPlay:
             raise ValueError("a game limit needs --streams 1")
         self.engine.set_game_limit(games)
 
+    def fetch(self):
+        """sync + finished games off the device; `drain` then formats them on the host while the GPU does something else"""
+        for e in self.engines:
+            e.fetch()
+
     def drain(self):
         lines = []
         for e in self.engines:

@@ -250,6 +250,13 @@ int azh_engine_timing(azh_engine *e, azh_timing *out);
  * result; one compact object per line).  Writes whole lines only; *used = bytes
  * written, *n_games = lines written; call again while *n_games > 0. */
 int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, int32_t *n_games);
+/* Takes the finished games off the device without formatting them: waits for the work enqueued so far, copies the record
+ * ring to the host and empties it; the next azh_engine_drain_json formats what was fetched and does not touch the device.
+ * A host loop that calls fetch, enqueues its next azh_engine_run and only then drains has the formatting and its own file
+ * writes running under that run instead of in front of it (the reference's workers write their games from their own
+ * threads, cpp/self_play_client.cpp:637-642: there, too, nobody waits for a game to be written).  Optional: a drain with
+ * nothing fetched fetches by itself. */
+int azh_engine_fetch(azh_engine *e);
 /* The line of ONE finished-game record (the words between two ring headers, as the device loop leaves them: 8-word header
  * {magic, slot, uid, plies, result, words, random_ply + 1, kind}, then per ply {x lo, x hi, o lo, o hi, move | nd << 16, 0,
  * nd x (move | visits << 16)}) exactly as azh_engine_drain_json writes it, without the newline: what the reference's
