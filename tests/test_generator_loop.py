@@ -1,0 +1,164 @@
+"""The host loop of accelerated_generate_games.py on the CPU: the script itself, run in a child process, with the engine behind
+`selfplay.SelfPlay` replaced by a recording stand-in (no device, no library).  What is checked is the order of the calls —
+since round 3 the next run is enqueued BEFORE the finished games of the last one are formatted and written — and that no game
+is written twice or lost on the ways out of the loop (SIGTERM as looper.py sends it, --max-seconds, --game-count).
+"""
+import json
+import os
+import signal
+import subprocess
+import sys
+import time
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+STUB = r'''
+import json, os, runpy, sys, time
+sys.path.insert(0, %(root)r)
+from ataxxzero_amd import model, selfplay
+
+calls = []
+LOG = %(log)r
+
+
+class Net:
+    blocks, filters = 12, 128
+
+
+class FakeSelfPlay:
+    """Every run "finishes" three games; they become visible to the host at the next fetch (or fetching drain)."""
+
+    def __init__(self, conv, bn, games, visits, **kw):
+        self.net = Net()
+        self.games = games
+        self.in_flight = []      # games of the runs enqueued and not yet fetched
+        self.fetched = []
+        self.next_game = 0
+        self.limit = None
+        self.counters = dict.fromkeys(["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
+                                       "edge_overflow", "reroot_nodes", "reroot_edges", "ring_overflow", "cache_hits",
+                                       "parked", "reroot_spills"], 0)
+        calls.append(["create", games, visits])
+
+    def set_emit_order(self, by_uid):
+        calls.append(["emit_order", bool(by_uid)])
+
+    def set_game_limit(self, n):
+        self.limit = n
+        calls.append(["limit", n])
+
+    def run(self, iterations):
+        calls.append(["run", iterations])
+        for _ in range(3):
+            if self.limit is None or self.next_game < self.limit:
+                self.in_flight.append(self.next_game)
+                self.next_game += 1
+        self.counters["nn_evals"] += 1000 * iterations
+        self.counters["steps"] += 1000 * iterations
+
+    def fetch(self):
+        calls.append(["fetch"])
+        time.sleep(0.01)         # the wait for the GPU
+        self.fetched += self.in_flight
+        self.counters["games"] += len(self.in_flight)
+        self.in_flight = []
+
+    def drain(self):
+        if not self.fetched:
+            self.fetch()
+            calls[-1] = ["fetch_in_drain"]
+        out, self.fetched = self.fetched, []
+        calls.append(["drain", len(out)])
+        return [json.dumps({"game": g}).encode() for g in out]
+
+    def stats(self):
+        calls.append(["stats"])
+        return dict(self.counters)
+
+    def close(self):
+        calls.append(["close"])
+        with open(LOG, "w") as f:
+            json.dump(calls, f)
+
+
+selfplay.SelfPlay = FakeSelfPlay
+selfplay.select_device = lambda index: 0
+model.load_model = lambda path: ([], [])
+sys.argv = ["accelerated_generate_games.py"] + %(argv)r
+runpy.run_path(os.path.join(%(root)r, "accelerated_generate_games.py"), run_name="__main__")
+'''
+
+
+def launch(tmp_path, argv, env=None):
+    out = str(tmp_path / "games-0.json")
+    log = str(tmp_path / "calls.json")
+    code = STUB % {"root": ROOT, "log": log, "argv": ["--network", "none.npy", "--output-games", out] + argv}
+    e = dict(os.environ)
+    e.pop("AZH_GAME_COUNT", None)
+    e.pop("AZH_SEQUENTIAL_DRAIN", None)
+    e.update(env or {})
+    proc = subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return proc, out, log
+
+
+def finish(proc, out, log):
+    text = proc.communicate(timeout=60)[0].decode()
+    games = [json.loads(l)["game"] for l in open(out)] if os.path.exists(out) else []
+    calls = json.load(open(log)) if os.path.exists(log) else None
+    return text, games, calls
+
+
+def loop_calls(calls):
+    return [c[0] for c in calls if c[0] in ("run", "fetch", "fetch_in_drain", "drain")]
+
+
+def test_next_run_is_enqueued_before_the_games_are_formatted(tmp_path):
+    proc, out, log = launch(tmp_path, ["--max-seconds", "0.3"])
+    text, games, calls = finish(proc, out, log)
+    assert proc.returncode == 0, text
+    seq = loop_calls(calls)
+    assert seq[:4] == ["run", "fetch", "run", "drain"]
+    # steady state: fetch, run, drain — the drain never has to wait for the device itself
+    body = seq[1:]
+    rounds = len(body) // 3
+    assert rounds >= 3
+    assert body[:3 * (rounds - 1)] == ["fetch", "run", "drain"] * (rounds - 1)
+    # the way out: the run still in flight is fetched by a last drain, so every finished game is written exactly once
+    assert seq[-2:] == ["fetch_in_drain", "drain"]
+    assert games == list(range(len(games))) and len(games) == 3 * seq.count("run")
+    assert "Totals: " in text and "all game slots shutdown." in text
+
+
+def test_sequential_order_on_request_and_with_a_game_target(tmp_path):
+    proc, out, log = launch(tmp_path, ["--max-seconds", "0.2"], env={"AZH_SEQUENTIAL_DRAIN": "1"})
+    text, games, calls = finish(proc, out, log)
+    assert proc.returncode == 0, text
+    seq = loop_calls(calls)
+    assert "fetch" not in seq and seq[:3] == ["run", "fetch_in_drain", "drain"]
+    assert games == list(range(3 * seq.count("run")))
+
+    sub = tmp_path / "target"
+    sub.mkdir()
+    proc, out, log = launch(sub, ["--game-count", "10"])
+    text, games, calls = finish(proc, out, log)
+    assert proc.returncode == 0, text
+    seq = loop_calls(calls)
+    assert "fetch" not in seq                       # with a target the rounds stay sequential (counters read every round)
+    assert ["limit", 10] in calls and ["create", 10, 100] in calls
+    assert games == list(range(10))                 # exactly the games below the limit, then the script ends by itself
+
+
+def test_sigterm_as_looper_sends_it_ends_the_run_within_its_two_seconds(tmp_path):
+    proc, out, log = launch(tmp_path, [])
+    deadline = time.time() + 20
+    while time.time() < deadline and not (os.path.exists(out) and os.path.getsize(out) > 200):
+        time.sleep(0.05)
+    t0 = time.time()
+    proc.send_signal(signal.SIGTERM)                # looper.py:57-64: SIGTERM, then kill after 2 s
+    text, games, calls = finish(proc, out, log)
+    assert time.time() - t0 < 2.0
+    assert proc.returncode == 0, text
+    seq = loop_calls(calls)
+    assert seq[-1] == "drain" and calls[-1] == ["close"]
+    assert games == list(range(len(games))) and len(games) == 3 * seq.count("run")
