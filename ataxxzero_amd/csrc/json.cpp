@@ -26,11 +26,126 @@ static void move_string(uint32_t mv, std::string &out)
     out.push_back((char)('1' + to / 7));
 }
 
-// nlohmann::json 3.x writes a double as the shortest digit string that reads back as the same double (Grisu2), laid out
-// by detail::dtoa_impl::format_buffer with min_exp = -4, max_exp = 15: plain decimals while the decimal point lies within
-// that many digits of the first digit (0.0001, 0.0025, 1.0), d[.ddd]e-XX with at least two exponent digits outside
-// (2.5e-05).  Python's repr(float) lays the values of [0, 1] out the same way (tests/test_json_format.py compares whole
-// lines with json.dumps).  std::to_chars alone would pick "5e-04" for 1 / 2000: shorter, and not what the reference writes.
+// The digits of a double as nlohmann::json (3.1+) finds them: Grisu2 (F. Loitsch, "Printing floating-point numbers quickly
+// and accurately with integers", PLDI 2010) with the 64-bit "do-it-yourself" floats, alpha = -60 / gamma = -32 and cached
+// powers of ten in steps of 10^8 that the library uses.  Grisu2 is shortest in ~99.9 % of the cases, not in all: 0.0976823894238616
+// is written 0.09768238942386159 — and a `dists` value is written the reference's way only if it is written THAT way, so the
+// algorithm is restated here instead of asking std::to_chars for the shortest digits (tests/test_json_format.py compares with
+// the library itself, oracle/json_entry_dump.cpp).  Only the two cached powers that are exact in 64 bits are carried (10^4,
+// 10^12): they serve every double in [7.3e-12, 32767] — a visit ratio is in [1/60000, 1]; outside, shortest digits.
+namespace grisu {
+
+struct Fp {
+    uint64_t f;
+    int e;
+};
+
+static inline Fp mul(Fp x, Fp y)  // upper 64 bits of the product, rounded half up
+{
+    const unsigned __int128 p = (unsigned __int128)x.f * y.f + ((unsigned __int128)1 << 63);
+    return {(uint64_t)(p >> 64), x.e + y.e + 64};
+}
+
+static inline Fp normalize(Fp x)
+{
+    while (!(x.f >> 63)) {
+        x.f <<= 1;
+        x.e--;
+    }
+    return x;
+}
+
+// digits (no leading zeros) and exponent with value = digits * 10^exponent; false if v is outside the supported range
+static bool digits(double v, char *buf, int &len, int &dec_exp)
+{
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    const uint64_t F = bits & ((1ull << 52) - 1);
+    const int E = (int)(bits >> 52) & 0x7FF;
+    if (E == 0 || E == 0x7FF)
+        return false;
+    const Fp val = {F | (1ull << 52), E - 1075};
+    // the neighbours' midpoints: every decimal in (m-, m+) reads back as v
+    const bool lower_closer = F == 0 && E > 1;
+    const Fp mp = {2 * val.f + 1, val.e - 1};
+    const Fp mm = lower_closer ? Fp{4 * val.f - 1, val.e - 2} : Fp{2 * val.f - 1, val.e - 1};
+    const Fp w_plus = normalize(mp);
+    const Fp w_minus = {mm.f << (mm.e - w_plus.e), w_plus.e};
+    const Fp w = normalize(val);
+    // cached power 10^k with alpha <= e_w + e_c + 64 <= gamma
+    const int f = -60 - w_plus.e - 1;
+    const int k = (f * 78913) / (1 << 18) + (f > 0 ? 1 : 0);
+    const int index = (300 + k + 7) / 8;
+    Fp c;
+    int ck;
+    if (index == 38) {
+        c = {0x9C40000000000000ull, -50};  // 10^4
+        ck = 4;
+    } else if (index == 39) {
+        c = {0xE8D4A51000000000ull, -24};  // 10^12
+        ck = 12;
+    } else {
+        return false;
+    }
+    const Fp W = mul(w, c), Wm = mul(w_minus, c), Wp = mul(w_plus, c);
+    // one unit of safety on either side: the products are off by at most one
+    const Fp M_minus = {Wm.f + 1, Wm.e}, M_plus = {Wp.f - 1, Wp.e};
+    dec_exp = -ck;
+    uint64_t delta = M_plus.f - M_minus.f, dist = M_plus.f - W.f;
+    const int sh = -M_plus.e;
+    const uint64_t one = 1ull << sh;
+    uint32_t p1 = (uint32_t)(M_plus.f >> sh);
+    uint64_t p2 = M_plus.f & (one - 1);
+    auto round_weed = [&](uint64_t rest, uint64_t ten_k) {
+        // step the last digit down while that brings the number closer to w without leaving the interval
+        while (rest < dist && delta - rest >= ten_k && (rest + ten_k < dist || dist - rest > rest + ten_k - dist)) {
+            buf[len - 1]--;
+            rest += ten_k;
+        }
+    };
+    uint32_t pow10 = 1;
+    int n = 1;
+    while (n < 10 && p1 >= pow10 * 10ull) {
+        pow10 *= 10;
+        n++;
+    }
+    len = 0;
+    while (n > 0) {  // the integral part, digit by digit
+        const uint32_t d = p1 / pow10;
+        p1 %= pow10;
+        buf[len++] = (char)('0' + d);
+        n--;
+        const uint64_t rest = ((uint64_t)p1 << sh) + p2;
+        if (rest <= delta) {
+            dec_exp += n;
+            round_weed(rest, (uint64_t)pow10 << sh);
+            return true;
+        }
+        pow10 /= 10;
+    }
+    int m = 0;
+    for (;;) {  // the fractional part
+        p2 *= 10;
+        const uint64_t d = p2 >> sh;
+        p2 &= one - 1;
+        buf[len++] = (char)('0' + d);
+        m++;
+        delta *= 10;
+        dist *= 10;
+        if (p2 <= delta)
+            break;
+    }
+    dec_exp -= m;
+    round_weed(p2, one);
+    return true;
+}
+
+}  // namespace grisu
+
+// nlohmann::json writes a double as the digits above laid out by detail::dtoa_impl::format_buffer with min_exp = -4,
+// max_exp = 15: plain decimals while the decimal point lies within that many digits of the first digit (0.0001, 0.0025,
+// 1.0), d[.ddd]e-XX with at least two exponent digits outside (2.5e-05).  (std::to_chars alone would pick "5e-04" for
+// 1 / 2000: shorter, and not what the reference writes.)
 static void append_double(double v, std::string &out)
 {
     if (v == 0.0) {
@@ -41,16 +156,21 @@ static void append_double(double v, std::string &out)
         out += '-';
         v = -v;
     }
-    char tmp[48];
-    auto r = std::to_chars(tmp, tmp + sizeof(tmp) - 1, v, std::chars_format::scientific);  // d[.ddd]e[+-]XX, shortest digits
-    *r.ptr = 0;
-    char digits[24];
-    int k = 0;
-    const char *p = tmp;
-    for (; *p && *p != 'e'; p++)
-        if (*p != '.')
-            digits[k++] = *p;
-    const int n = atoi(p + 1) + 1;  // the decimal point sits after the n-th digit
+    char digits[40];
+    int k = 0, n = 0;  // k digits; the decimal point sits after the n-th
+    int dec_exp = 0;
+    if (grisu::digits(v, digits, k, dec_exp)) {
+        n = k + dec_exp;
+    } else {
+        char tmp[48];
+        auto r = std::to_chars(tmp, tmp + sizeof(tmp) - 1, v, std::chars_format::scientific);  // d[.ddd]e[+-]XX, shortest digits
+        *r.ptr = 0;
+        const char *p = tmp;
+        for (; *p && *p != 'e'; p++)
+            if (*p != '.')
+                digits[k++] = *p;
+        n = atoi(p + 1) + 1;
+    }
     if (k <= n && n <= 15) {
         out.append(digits, (size_t)k);
         out.append((size_t)(n - k), '0');

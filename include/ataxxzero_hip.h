@@ -261,7 +261,7 @@ int azh_engine_fetch(azh_engine *e);
  * {magic, slot, uid, plies, result, words, random_ply + 1, kind}, then per ply {x lo, x hi, o lo, o hi, move | nd << 16, 0,
  * nd x (move | visits << 16)}) exactly as azh_engine_drain_json writes it, without the newline: what the reference's
  * `entry.dump()` gives (cpp/self_play_client.cpp:565-578,639-641: nlohmann::json — sorted keys, no whitespace, floats as
- * shortest round-trip digits, plain decimals from 1e-4 up, d.ddde-XX below).  Host code only, usable without a device.
+ * the digits its Grisu2 finds, plain decimals from 1e-4 up, d.ddde-XX below).  Host code only, usable without a device.
  * *used = bytes the line has; -6 if `cap` is smaller (nothing written), -2 if the words are not a well-formed record.
  * with_ids: the arena's two extra keys (slot, uid). */
 int azh_format_record_json(const uint32_t *rec, int64_t words, int32_t with_ids, char *buf, int64_t cap, int64_t *used);

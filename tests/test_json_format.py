@@ -1,13 +1,19 @@
 """The game line the host writes for a finished-game record (csrc/json.cpp) — checked on the CPU, no device needed.
 
-The reference's client builds each entry as an nlohmann::json object and writes `entry.dump()` + newline
-(cpp/self_play_client.cpp:512,565-578,637-642): keys sorted, no whitespace, floats as the shortest digits that round-trip,
-laid out by nlohmann's format_buffer (plain decimals between 1e-4 and 1e15, d.ddde-XX outside).  `json.dumps(entry,
-sort_keys=True, separators=(",", ":"))` writes the same bytes for values in [0, 1] — Python's repr(float) uses the same
-digits and the same lay-out there — so it is the independent statement these lines are compared with, byte for byte.
+The reference's client builds each entry as an nlohmann::json object and writes it with `stream << entry` + newline
+(cpp/self_play_client.cpp:512,565-578,637-642): keys sorted, no whitespace, doubles as Grisu2 finds their digits, laid out by
+nlohmann's format_buffer (plain decimals between 1e-4 and 1e15, d.ddde-XX outside).  Two independent statements of that:
+
+* the library itself — nlohmann::json 3.1.1 is installed in this image (/opt/conda/include/json.hpp; third party, not part
+  of the reference) and oracle/json_entry_dump.cpp builds and streams the entry with it exactly as the reference's code
+  does: whole lines must be equal byte for byte;
+* Python's `json.dumps(entry, sort_keys=True, separators=(",", ":"))`: the same bytes except for the one double in a
+  thousand that Grisu2 writes with 17 digits where 16 suffice (repr always finds the shortest) — compared with those
+  doubles normalised, and value for value.
 """
 import ctypes
 import json
+import re
 
 import numpy as np
 import pytest
@@ -59,16 +65,23 @@ def dumped(entry):
     return json.dumps(entry, sort_keys=True, separators=(",", ":")).encode()
 
 
+def shortest(line):
+    """every double of the line rewritten with its shortest digits (what json.dumps writes); nothing else touched"""
+    return re.sub(rb"\d+\.\d+(?:e[-+]\d+)?|\d+e[-+]\d+", lambda m: repr(float(m.group())).encode(), line)
+
+
 @pytest.mark.parametrize("visits_hi", [1, 7, 400, 2000, 60000])
-def test_lines_equal_the_sorted_compact_dump_byte_for_byte(visits_hi):
+def test_lines_equal_the_sorted_compact_dump(visits_hi):
     rng = np.random.default_rng(visits_hi)
     for case in range(40):
         rec, entry = random_record(rng, plies=int(rng.integers(1, 30)), visits_hi=visits_hi,
                                    random_ply=int(rng.integers(0, 120)) if case % 4 == 3 else None,
                                    result=1 + case % 2, zero_total_at=0 if case % 10 == 9 else None)
-        assert link.format_record_json(rec) == dumped(entry)
+        line = link.format_record_json(rec)
+        assert json.loads(line) == entry                     # every value, exactly
+        assert shortest(line) == dumped(entry)               # keys, order, separators, integers, lay-out of the doubles
         with_ids = dict(entry, slot=3, uid=77)
-        assert link.format_record_json(rec, with_ids=True) == dumped(with_ids)
+        assert shortest(link.format_record_json(rec, with_ids=True)) == dumped(with_ids)
 
 
 def test_small_ratios_are_written_as_nlohmann_writes_them():
@@ -107,3 +120,79 @@ def test_malformed_records_are_refused():
     buf = np.zeros(16, dtype=np.uint8)
     rc = link.load().azh_format_record_json(rec.ctypes.data, len(rec), 0, buf.ctypes.data, buf.nbytes, ctypes.byref(need))
     assert rc == -6 and need.value == len(link.format_record_json(rec))
+
+
+# ------------------------------------------------------------------ against the library the reference itself uses
+
+NLOHMANN = "/opt/conda/include/json.hpp"     # nlohmann::json 3.1.1 ships with this image (third party, not the reference)
+
+
+@pytest.fixture(scope="module")
+def entry_dump(tmp_path_factory):
+    """oracle/json_entry_dump.cpp: builds the entry with nlohmann::json exactly as cpp/self_play_client.cpp:512-578 does and
+    streams it as :639-641 does"""
+    import os
+    import subprocess
+    if not os.path.exists(NLOHMANN):
+        pytest.skip("nlohmann json.hpp is not installed here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path_factory.mktemp("nlohmann") / "json_entry_dump")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.dirname(NLOHMANN), "-o", exe,
+                           os.path.join(root, "oracle", "json_entry_dump.cpp")])
+
+    def run(records):
+        out = subprocess.run([exe], input=b"".join(np.ascontiguousarray(r, dtype=np.uint32).tobytes() for r in records),
+                             capture_output=True, check=True)
+        return out.stdout.split(b"\n")[:-1]
+    return run
+
+
+def test_lines_equal_what_nlohmann_json_itself_writes(entry_dump):
+    """Byte for byte, including the doubles for which Grisu2 — the library's algorithm — does NOT find the shortest
+    digits (json.dumps then differs from the reference, and so did this formatter while it asked std::to_chars)."""
+    rng = np.random.default_rng(2026)
+    records, entries = [], []
+    for case in range(120):
+        rec, entry = random_record(rng, plies=int(rng.integers(1, 60)), visits_hi=[1, 7, 100, 400, 800, 2000, 60000][case % 7],
+                                   random_ply=int(rng.integers(0, 120)) if case % 5 == 4 else None, result=1 + case % 2,
+                                   zero_total_at=0 if case % 11 == 10 else None)
+        records.append(rec)
+        entries.append(entry)
+    theirs = entry_dump(records)
+    assert len(theirs) == len(records)
+    not_shortest = 0
+    for rec, entry, line in zip(records, entries, theirs):
+        assert link.format_record_json(rec) == line
+        assert json.loads(line) == entry                 # same values either way
+        not_shortest += line != dumped(entry)
+    assert not_shortest > 0, "the sample should hold doubles that Grisu2 writes with 17 digits where 16 suffice"
+
+
+def test_every_visit_ratio_up_to_800_visits_is_written_as_the_library_writes_it(entry_dump):
+    """n / N for every N <= 800 and every n <= N (the configs' visit counts: 100, 200, 400, 800), two per ply entry, and a
+    sample of ratios up to the engine's limit of 60000 visits"""
+    head = [MAGIC, 0, 0, 0, 1, 0, 0, 0]
+    words, plies = list(head), 0
+    records = []
+
+    def flush():
+        nonlocal words, plies
+        if plies:
+            words[3], words[5] = plies, len(words)
+            records.append(np.array(words, dtype=np.uint32))
+        words, plies = list(head), 0
+
+    rng = np.random.default_rng(7)
+    pairs = [(n, N) for N in range(1, 801) for n in range(1, N + 1)]
+    pairs += [(int(rng.integers(1, N + 1)), N) for N in rng.integers(801, 60001, size=40000)]
+    for n, N in pairs:
+        a, b = (0 | 8 << 8), (1 | 9 << 8)                # "a1b2": n, "b1c2": N - n
+        ply = [1, 0, 2, 0, a | (2 if N > n else 1) << 16, 0, a | n << 16] + ([b | (N - n) << 16] if N > n else [])
+        words += ply
+        plies += 1
+        if plies == 2000:
+            flush()
+    flush()
+    theirs = entry_dump(records)
+    for rec, line in zip(records, theirs):
+        assert link.format_record_json(rec) == line
