@@ -40,6 +40,7 @@ class FakeSelfPlay:
                                        "edge_overflow", "reroot_nodes", "reroot_edges", "ring_overflow", "cache_hits",
                                        "parked", "reroot_spills"], 0)
         calls.append(["create", games, visits])
+        calls.append(["seed", kw.get("seed")])
 
     def set_emit_order(self, by_uid):
         calls.append(["emit_order", bool(by_uid)])
@@ -83,15 +84,15 @@ class FakeSelfPlay:
 
 
 selfplay.SelfPlay = FakeSelfPlay
-selfplay.select_device = lambda index: 0
+selfplay.select_device = lambda index: calls.append(["device_for_index", index]) or index
 model.load_model = lambda path: ([], [])
 sys.argv = ["accelerated_generate_games.py"] + %(argv)r
 runpy.run_path(os.path.join(%(root)r, "accelerated_generate_games.py"), run_name="__main__")
 '''
 
 
-def launch(tmp_path, argv, env=None):
-    out = str(tmp_path / "games-0.json")
+def launch(tmp_path, argv, env=None, name="games-0.json"):
+    out = str(tmp_path / name)
     log = str(tmp_path / "calls.json")
     code = STUB % {"root": ROOT, "log": log, "argv": ["--network", "none.npy", "--output-games", out] + argv}
     e = dict(os.environ)
@@ -162,3 +163,18 @@ def test_sigterm_as_looper_sends_it_ends_the_run_within_its_two_seconds(tmp_path
     seq = loop_calls(calls)
     assert seq[-1] == "drain" and calls[-1] == ["close"]
     assert games == list(range(len(games))) and len(games) == 3 * seq.count("run")
+
+
+def test_looper_style_process_index_picks_device_and_seed(tmp_path):
+    """looper.py:70-74 starts N generators on games/model-%03i-%i.json: the trailing index is the GPU the process takes and
+    the offset of its Philox seed (one process per GPU, distinct streams, no collective)"""
+    seen = []
+    for index in (0, 3, 7):
+        sub = tmp_path / str(index)
+        sub.mkdir()
+        proc, out, log = launch(sub, ["--max-seconds", "0.05", "--seed", "100"], name="model-004-%d.json" % index)
+        text, games, calls = finish(proc, out, log)
+        assert proc.returncode == 0, text
+        assert ["device_for_index", index] in calls and ["seed", 100 + index] in calls
+        seen.append(index)
+    assert seen == [0, 3, 7]
