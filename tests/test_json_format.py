@@ -196,3 +196,23 @@ def test_every_visit_ratio_up_to_800_visits_is_written_as_the_library_writes_it(
     theirs = entry_dump(records)
     for rec, line in zip(records, theirs):
         assert link.format_record_json(rec) == line
+
+
+def test_formatter_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """csrc/json.cpp compiled for the host with ASan + UBSan and driven with 30,000 well-formed and damaged records
+    (tests/fuzz/json_fuzz_driver.cpp): no report, damaged records refused, short buffers reported"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "json_fuzz")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+           "-I" + os.path.join(root, "ataxxzero_amd", "csrc"), "-o", exe,
+           os.path.join(root, "tests", "fuzz", "json_fuzz_driver.cpp"), os.path.join(root, "ataxxzero_amd", "csrc", "json.cpp")]
+    built = subprocess.run(cmd, capture_output=True)
+    if built.returncode != 0:
+        pytest.skip("no sanitizer build here: " + built.stderr.decode()[-300:])
+    res = subprocess.run([exe, "30000"], capture_output=True, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    formatted, refused, small = (int(x) for x in re.findall(rb"\d+", res.stdout))
+    assert formatted > 3000 and refused > 3000 and small > 100
