@@ -1489,6 +1489,7 @@ using namespace azh;
 // ------------------------------------------------------------------ host
 
 std::string azh_format_game_json(const uint32_t *rec, size_t words, bool with_ids);  // json.cpp
+bool azh_record_well_formed(const uint32_t *rec, size_t avail, uint32_t max_plies, const char **why);
 
 struct azh_engine {
     azh_config cfg;
@@ -1505,6 +1506,11 @@ struct azh_engine {
     size_t pending_pos = 0;
     // records taken off the device (azh_engine_fetch) and not yet formatted
     std::vector<uint32_t> staged;
+    // an explicit azh_engine_fetch covers the drain sequence that follows it: until that sequence has ended (a drain call
+    // that hands out no game) a drain with nothing staged returns empty instead of fetching — the caller has enqueued
+    // its next run in between, and a fetch would wait for that run
+    bool fetch_covers_drain = false;
+    long long implicit_fetches = 0;  // fetches made by azh_engine_drain_json itself (azh_engine_implicit_fetches)
     // uid-ordered emission: finished games wait here until every game with a smaller uid has been handed out or
     // is known to have been dropped ("" = dropped)
     bool emit_by_uid = false;
@@ -2097,11 +2103,12 @@ extern "C" int azh_engine_timing(azh_engine *e, azh_timing *out)
 // Takes the finished-game records off the device: waits for the work enqueued so far, copies the record ring to the host
 // and empties it.  azh_engine_drain_json formats what was fetched without touching the device, so a caller may start its
 // next run between the two calls and the formatting (a quarter of a millisecond per 150-ply game) and its own file
-// writes happen under that run instead of in front of it.  Calling it is optional: a drain with nothing fetched fetches.
-extern "C" int azh_engine_fetch(azh_engine *e)
+// writes happen under that run instead of in front of it.  Calling azh_engine_fetch is optional: a drain with nothing
+// fetched fetches — but never inside the drain sequence that follows an explicit fetch (up to and including the first
+// drain call that hands out no game): there "nothing staged" means "no game finished", and a fetch would wait for the run
+// the caller has enqueued in between (round 3's loop did exactly that and ran sequentially without saying so).
+static int fetch_records(azh_engine *e)
 {
-    if (!e)
-        return azh_fail(-1, "azh_engine_fetch: null engine");
     AZH_HIP(hipStreamSynchronize(e->stream));
     u64 head = 0;
     AZH_HIP(hipMemcpy(&head, e->P.ring_head, 8, hipMemcpyDeviceToHost));
@@ -2122,6 +2129,18 @@ extern "C" int azh_engine_fetch(azh_engine *e)
     return 0;
 }
 
+extern "C" int azh_engine_fetch(azh_engine *e)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_fetch: null engine");
+    const int rc = fetch_records(e);
+    if (rc == 0)
+        e->fetch_covers_drain = true;
+    return rc;
+}
+
+extern "C" long long azh_engine_implicit_fetches(const azh_engine *e) { return e ? e->implicit_fetches : -1; }
+
 // the fetched records -> lines (in uid order where that is asked for); host work only
 static void format_staged(azh_engine *e)
 {
@@ -2136,11 +2155,13 @@ static void format_staged(azh_engine *e)
             pos++;
             continue;
         }
-        const size_t words = host[pos + 5];
-        if (words < 8 || pos + words > host.size()) {
+        // (a payload word may equal the magic — board halves are arbitrary bit patterns: a header counts only if the
+        // record it announces is whole and its ply structure walks to its end exactly)
+        if (!azh_record_well_formed(host.data() + pos, host.size() - pos, (uint32_t)e->P.max_plies, nullptr)) {
             pos++;
             continue;
         }
+        const size_t words = host[pos + 5];
         order.emplace_back(host[pos + 2], pos);
         pos += words;
     }
@@ -2181,13 +2202,18 @@ extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int6
     if (e->pending_pos >= e->pending.size()) {
         e->pending.clear();
         e->pending_pos = 0;
-        if (e->staged.empty()) {
-            const int rc = azh_engine_fetch(e);
+        if (e->staged.empty() && !e->fetch_covers_drain) {
+            // a caller that never fetches: the drain does (and waits for whatever is enqueued)
+            e->implicit_fetches++;
+            const int rc = fetch_records(e);
             if (rc)
                 return rc;
+            e->fetch_covers_drain = true;  // one fetch per drain sequence: the call that ends it finds nothing new
         }
         if (!e->staged.empty())
             format_staged(e);
+        if (e->pending.empty())
+            e->fetch_covers_drain = false;  // the sequence the explicit fetch covered ends with this (empty) call
     }
     while (e->pending_pos < e->pending.size()) {
         const std::string &line = e->pending[e->pending_pos];

@@ -6,6 +6,7 @@
 // (serialize_board_for_json :88-107); dists: expanded root edges -> visits / total.
 #include <algorithm>
 #include <charconv>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -148,6 +149,10 @@ static bool digits(double v, char *buf, int &len, int &dec_exp)
 // 1 / 2000: shorter, and not what the reference writes.)
 static void append_double(double v, std::string &out)
 {
+    if (!std::isfinite(v)) {
+        out += "null";  // nlohmann's dump_float writes null for NaN and the infinities
+        return;
+    }
     if (v == 0.0) {
         out += "0.0";
         return;
@@ -169,7 +174,7 @@ static void append_double(double v, std::string &out)
         for (; *p && *p != 'e'; p++)
             if (*p != '.')
                 digits[k++] = *p;
-        n = atoi(p + 1) + 1;
+        n = (*p == 'e' ? atoi(p + 1) : 0) + 1;
     }
     if (k <= n && n <= 15) {
         out.append(digits, (size_t)k);
@@ -261,6 +266,37 @@ std::string azh_format_game_json(const uint32_t *rec, size_t words, bool with_id
     return out;
 }
 
+// Is what starts at `rec` (at most `avail` words of it readable) a whole, well-formed record?  The ply structure must
+// walk to the record's end exactly.  Used by azh_format_record_json and by the engine's drain when it looks for the next
+// header after a damaged record: a payload word may equal the magic (board halves are arbitrary bit patterns), and only a
+// header whose record passes this walk is taken for one.
+bool azh_record_well_formed(const uint32_t *rec, size_t avail, uint32_t max_plies, const char **why)
+{
+    const char *dummy;
+    if (!why)
+        why = &dummy;
+    *why = "not a finished-game record";
+    if (avail < 8 || rec[0] != 0x415A4847u /* "AZHG", engine.hip RING_MAGIC */ || rec[5] < 8 || (size_t)rec[5] > avail)
+        return false;
+    if (rec[7] == 1)  // the marker a dropped game leaves: a header and nothing else
+        return rec[5] == 8;
+    *why = "header fields out of range";
+    if (rec[7] > 2 || rec[4] > 2 || (max_plies && rec[3] > max_plies))
+        return false;
+    *why = "a ply runs past the record's words";
+    size_t pos = 8;
+    for (uint32_t p = 0; p < rec[3]; p++) {
+        if (pos + 6 > rec[5])
+            return false;
+        const uint32_t nd = rec[pos + 4] >> 16;
+        if (nd > 256 || pos + 6 + nd > rec[5])
+            return false;
+        pos += 6 + nd;
+    }
+    *why = "the plies do not fill the record";
+    return pos == rec[5];
+}
+
 // One record -> its line, for callers that hold records themselves and for the CPU-side test of the format: host code only,
 // no device is touched.
 extern "C" int azh_format_record_json(const uint32_t *rec, int64_t words, int32_t with_ids, char *buf, int64_t cap,
@@ -269,15 +305,13 @@ extern "C" int azh_format_record_json(const uint32_t *rec, int64_t words, int32_
     if (!rec || !buf || !used)
         return azh_fail(-1, "azh_format_record_json: null argument");
     *used = 0;
-    if (words < 8 || rec[0] != 0x415A4847u /* "AZHG", engine.hip RING_MAGIC */ || rec[5] < 8 || (int64_t)rec[5] > words)
-        return azh_fail(-2, "azh_format_record_json: not a finished-game record (%lld words handed over, header says %u)",
-                        (long long)words, words >= 8 ? rec[5] : 0u);
-    size_t pos = 8;
-    for (uint32_t p = 0; p < rec[3]; p++) {
-        if (pos + 6 > rec[5] || pos + 6 + (rec[pos + 4] >> 16) > rec[5])
-            return azh_fail(-2, "azh_format_record_json: ply %u of %u runs past the record's %u words", p, rec[3], rec[5]);
-        pos += 6 + (rec[pos + 4] >> 16);
-    }
+    const char *why = nullptr;
+    if (words < 8 || !azh_record_well_formed(rec, (size_t)words, 0u, &why))
+        return azh_fail(-2, "azh_format_record_json: %s (%lld words handed over, header says %u words, %u plies)",
+                        why ? why : "not a finished-game record", (long long)words, words >= 8 ? rec[5] : 0u,
+                        words >= 8 ? rec[3] : 0u);
+    if (rec[7] == 1)
+        return azh_fail(-2, "azh_format_record_json: the record is the marker of a dropped game, it has no line");
     const std::string line = azh_format_game_json(rec, rec[5], with_ids != 0);
     *used = (int64_t)line.size();
     if ((int64_t)line.size() > cap)

@@ -100,6 +100,7 @@ SIGNATURES = {
     "azh_engine_timing_reset": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_timing": (ctypes.c_int, [_vp, _P(Timing)]),
     "azh_engine_fetch": (ctypes.c_int, [_vp]),
+    "azh_engine_implicit_fetches": (ctypes.c_longlong, [_vp]),
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
     "azh_format_record_json": (ctypes.c_int, [_vp, ctypes.c_int64, _i32, _vp, ctypes.c_int64, _P(ctypes.c_int64)]),
     "azh_engine_set_emit_order": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -421,6 +422,10 @@ class Engine:
         """Wait for the work enqueued so far and take its finished games off the device; the next drain_json formats
         them without touching the GPU (so the next run can be enqueued in between)."""
         check(load().azh_engine_fetch(self.h))
+
+    def implicit_fetches(self):
+        """Times a drain had to fetch by itself (= waited for the device); 0 in a loop that fetches before it drains."""
+        return int(load().azh_engine_implicit_fetches(self.h))
 
     def drain_json(self):
         """Finished games since the last call, as a list of JSON lines (bytes, no newline)."""

@@ -255,8 +255,12 @@ int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, 
  * A host loop that calls fetch, enqueues its next azh_engine_run and only then drains has the formatting and its own file
  * writes running under that run instead of in front of it (the reference's workers write their games from their own
  * threads, cpp/self_play_client.cpp:637-642: there, too, nobody waits for a game to be written).  Optional: a drain with
- * nothing fetched fetches by itself. */
+ * nothing fetched fetches by itself — except inside the drain sequence that follows an explicit fetch (the calls up to and
+ * including the first one that returns *n_games == 0): those never touch the device, whatever was enqueued meanwhile. */
 int azh_engine_fetch(azh_engine *e);
+/* How many times azh_engine_drain_json had to fetch by itself (and so waited for the device) since the engine was created:
+ * 0 for a host loop that fetches explicitly before every drain sequence. */
+long long azh_engine_implicit_fetches(const azh_engine *e);
 /* The line of ONE finished-game record (the words between two ring headers, as the device loop leaves them: 8-word header
  * {magic, slot, uid, plies, result, words, random_ply + 1, kind}, then per ply {x lo, x hi, o lo, o hi, move | nd << 16, 0,
  * nd x (move | visits << 16)}) exactly as azh_engine_drain_json writes it, without the newline: what the reference's

@@ -27,13 +27,18 @@ class Net:
 
 
 class FakeSelfPlay:
-    """Every run "finishes" three games; they become visible to the host at the next fetch (or fetching drain)."""
+    """Every run "finishes" three games; they become visible to the host at the next fetch.  fetch / drain mirror the product:
+    `drain` is link.Engine.drain_json (it calls the library's drain until a call hands out no game) and `_drain_call` is
+    azh_engine_drain_json's state machine (csrc/engine.hip): a call with nothing pending and nothing staged fetches by
+    itself — and so waits for whatever run is enqueued — unless an explicit fetch covers the drain sequence."""
 
     def __init__(self, conv, bn, games, visits, **kw):
         self.net = Net()
         self.games = games
         self.in_flight = []      # games of the runs enqueued and not yet fetched
-        self.fetched = []
+        self.staged = []         # fetched, not yet formatted
+        self.covers = False      # an explicit fetch covers the drain sequence that follows it
+        self.old_semantics = bool(os.environ.get("FAKE_ROUND3_DRAIN"))   # round 3's library: every empty call fetched
         self.next_game = 0
         self.limit = None
         self.counters = dict.fromkeys(["steps", "nn_evals", "levels", "children", "new_moves", "plies", "games", "dropped",
@@ -58,20 +63,36 @@ class FakeSelfPlay:
         self.counters["nn_evals"] += 1000 * iterations
         self.counters["steps"] += 1000 * iterations
 
-    def fetch(self):
-        calls.append(["fetch"])
-        time.sleep(0.01)         # the wait for the GPU
-        self.fetched += self.in_flight
+    def _fetch_records(self):
+        time.sleep(0.01)         # the wait for the GPU: everything enqueued so far has to end
+        self.staged += self.in_flight
         self.counters["games"] += len(self.in_flight)
         self.in_flight = []
 
+    def fetch(self):
+        calls.append(["fetch"])
+        self._fetch_records()
+        self.covers = not self.old_semantics
+
+    def _drain_call(self):
+        if not self.staged and not self.covers:
+            calls.append(["fetch_in_drain"])
+            self._fetch_records()
+            self.covers = not self.old_semantics   # one fetch per drain sequence
+        out, self.staged = self.staged, []
+        if not out:
+            self.covers = False
+        return out
+
     def drain(self):
-        if not self.fetched:
-            self.fetch()
-            calls[-1] = ["fetch_in_drain"]
-        out, self.fetched = self.fetched, []
-        calls.append(["drain", len(out)])
-        return [json.dumps({"game": g}).encode() for g in out]
+        lines = []
+        while True:
+            got = self._drain_call()
+            if not got:
+                break
+            lines += got
+        calls.append(["drain", len(lines)])
+        return [json.dumps({"game": g}).encode() for g in lines]
 
     def stats(self):
         calls.append(["stats"])
@@ -120,15 +141,28 @@ def test_next_run_is_enqueued_before_the_games_are_formatted(tmp_path):
     assert proc.returncode == 0, text
     seq = loop_calls(calls)
     assert seq[:4] == ["run", "fetch", "run", "drain"]
-    # steady state: fetch, run, drain — the drain never has to wait for the device itself
+    # steady state: fetch, run, drain — and NO call of the drain sequence waits for the device (a fetch inside the drain
+    # would wait for the run that was just enqueued: the order would be sequential again without saying so)
+    assert "fetch_in_drain" not in seq
     body = seq[1:]
     rounds = len(body) // 3
     assert rounds >= 3
     assert body[:3 * (rounds - 1)] == ["fetch", "run", "drain"] * (rounds - 1)
-    # the way out: the run still in flight is fetched by a last drain, so every finished game is written exactly once
-    assert seq[-2:] == ["fetch_in_drain", "drain"]
+    # the way out: the run still in flight is fetched explicitly, so every finished game is written exactly once
+    assert seq[-2:] == ["fetch", "drain"]
     assert games == list(range(len(games))) and len(games) == 3 * seq.count("run")
     assert "Totals: " in text and "all game slots shutdown." in text
+
+
+def test_the_stand_in_would_have_caught_round_3s_implicit_fetch(tmp_path):
+    """With round 3's library semantics (a drain call that finds nothing staged always fetches) the loop's last drain call of
+    every round waits for the run that was just enqueued: the stand-in shows it, so the assertion above is not vacuous."""
+    proc, out, log = launch(tmp_path, ["--max-seconds", "0.2"], env={"FAKE_ROUND3_DRAIN": "1"})
+    text, games, calls = finish(proc, out, log)
+    assert proc.returncode == 0, text
+    seq = loop_calls(calls)
+    assert seq[:4] == ["run", "fetch", "run", "fetch_in_drain"]
+    assert games == list(range(len(games)))         # (correct games all the same: that is why nobody noticed)
 
 
 def test_sequential_order_on_request_and_with_a_game_target(tmp_path):
@@ -136,7 +170,7 @@ def test_sequential_order_on_request_and_with_a_game_target(tmp_path):
     text, games, calls = finish(proc, out, log)
     assert proc.returncode == 0, text
     seq = loop_calls(calls)
-    assert "fetch" not in seq and seq[:3] == ["run", "fetch_in_drain", "drain"]
+    assert "fetch" not in seq and seq[:3] == ["run", "fetch_in_drain", "drain"]   # sequential: the drain itself waits
     assert games == list(range(3 * seq.count("run")))
 
     sub = tmp_path / "target"

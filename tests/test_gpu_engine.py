@@ -120,6 +120,48 @@ def test_device_resident_selfplay_with_builtin_net(dtype, visits):
         assert all(min(d.values()) > 0 for d in entry["dists"])
 
 
+def test_overlapped_round_trip_never_waits_for_the_device_inside_the_drain():
+    """The generator's order — fetch, enqueue the next run, drain (accelerated_generate_games.py) — on the real library: no
+    call of the drain sequence may fetch by itself (it would wait for the run just enqueued, and the round would be
+    sequential again without saying so: round 3's loop did that), the drain must come back while that run is still in
+    flight, and the lines are the ones the sequential order gives."""
+    import time
+    conv, bn = model.random_init(2, 128, seed=2)
+    net = link.Net(conv, bn)
+    ocfg = orc.make_config(256, 24, seed=11, max_plies=400)
+
+    def engine():
+        return link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
+
+    seq, ovl = engine(), engine()
+    want = []
+    for _ in range(12):
+        seq.run(net, 300, link.DTYPE_F32)
+        want += seq.drain_json()
+    assert seq.implicit_fetches() == 12          # a caller that never fetches: one fetch per drain sequence, not two
+    lines, drain_s, rest_s, empty_rounds = [], 0.0, 0.0, 0
+    ovl.run(net, 300, link.DTYPE_F32)
+    for _ in range(11):
+        ovl.fetch()
+        ovl.run(net, 300, link.DTYPE_F32)
+        t0 = time.perf_counter()
+        got = ovl.drain_json()
+        t1 = time.perf_counter()
+        ovl.sync()                                # what is left of the run that was enqueued before the drain
+        rest_s += time.perf_counter() - t1
+        drain_s += t1 - t0
+        empty_rounds += not got
+        lines += got
+    ovl.fetch()
+    lines += ovl.drain_json()
+    assert ovl.implicit_fetches() == 0
+    assert lines == want and len(lines) > 100
+    # had the drain waited for the device, nothing of the run would be left after it
+    assert rest_s > 5 * drain_s or rest_s > 0.05, (drain_s, rest_s)
+    print("overlapped drain: %.1f ms formatting in all under %.1f ms of search left after it, %d of 11 rounds without a game"
+          % (1e3 * drain_s, 1e3 * rest_s, empty_rounds))
+
+
 def test_game_limit_plays_exactly_the_games_below_it_and_then_idles():
     """azh_engine_set_game_limit: uids 0 .. N - 1 are played (slot g: g, g + G, ...), a slot whose next game would be past
     the limit goes idle, and the games are the ones the unlimited engine plays under those uids."""

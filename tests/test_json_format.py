@@ -115,6 +115,19 @@ def test_malformed_records_are_refused():
     cut[3] += 1                                    # one ply more than the words hold
     with pytest.raises(link.AzhError):
         link.format_record_json(cut)
+    # the walk the drain's resynchronisation relies on (a payload word may equal the magic): the plies must fill the record
+    # exactly, the header fields must be in range, and a dropped game's marker is not a game
+    slack = np.concatenate([rec, np.zeros(3, dtype=np.uint32)])
+    slack[5] += 3
+    with pytest.raises(link.AzhError):
+        link.format_record_json(slack)
+    odd = rec.copy()
+    odd[4] = 7                                     # a result no game has
+    with pytest.raises(link.AzhError):
+        link.format_record_json(odd)
+    marker = np.array([rec[0], 5, 9, 17, 0, 8, 0, 1], dtype=np.uint32)
+    with pytest.raises(link.AzhError):
+        link.format_record_json(marker)
     # a buffer that is too small reports the size it needs instead of writing a partial line
     need = ctypes.c_int64(0)
     buf = np.zeros(16, dtype=np.uint8)
