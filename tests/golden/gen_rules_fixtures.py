@@ -3,7 +3,15 @@
 
 Run in the build container only (needs /root/reference, which never travels):
 
-    python tests/golden/gen_rules_fixtures.py
+    PYTHONHASHSEED=0 python tests/golden/gen_rules_fixtures.py
+    PYTHONHASHSEED=0 python tests/golden/gen_engine_fixtures.py     # engine_features.npz follows the position order
+
+Reproducible since round 4: the reference's `legal_moves()` builds its clone moves from a `set` of ("c", dest) tuples
+(ataxx_rules.py:134-157), so the ORDER of the list depends on the interpreter's string-hash seed; every draw this script
+makes from such a list (the move played, the successors recorded) is therefore made from the list sorted by UAI text, and
+the script refuses to run under any hash seed but 0, the one gen_engine_fixtures.py is run under.  (Rounds 1-3 drew from the
+unsorted list under an unrecorded hash seed: the vectors were the reference's own answers, but the recipe did not give the
+same positions twice.)
 
 Imports `ataxx_rules` and `uai_interface` from /root/reference unmodified
 (stdlib-only modules) and writes data-only fixtures next to this script:
@@ -70,6 +78,11 @@ def perft_table(max_depth):
     return table
 
 
+def in_uai_order(moves):
+    """the list `legal_moves()` returns, in an order that does not depend on the hash seed"""
+    return sorted(moves, key=uai_interface.uai_encode_move)
+
+
 def position_record(state, rng):
     moves = state.legal_moves()
     rec = {
@@ -80,7 +93,7 @@ def position_record(state, rng):
         "cells": list(state.board),
     }
     succ = {}
-    for m in rng.sample(moves, min(4, len(moves))):
+    for m in rng.sample(in_uai_order(moves), min(4, len(moves))):
         c = state.copy()
         c.move(m)
         succ[uai_interface.uai_encode_move(m)] = c.fen()
@@ -96,7 +109,7 @@ def random_positions(seed, n_games, keep_prob):
         for _ply in range(400):
             if rng.random() < keep_prob:
                 out.append(position_record(state, rng))
-            state.move(rng.choice(state.legal_moves()))
+            state.move(rng.choice(in_uai_order(state.legal_moves())))
             if state.result() is not None:
                 out.append(position_record(state, rng))  # terminal position
                 break
@@ -110,6 +123,8 @@ def dump_gz(name, obj):
 
 
 def main():
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        raise SystemExit("run as: PYTHONHASHSEED=0 python tests/golden/gen_rules_fixtures.py (see the docstring)")
     perfts = {}
     set_blockers(frozenset())
     perfts["noblock"] = perft_table(5)

@@ -26,7 +26,7 @@ def test_feature_rows_equal_engine_board_to_features():
             got = orc.features(orc.pos_from_fen(rec["fen"]))
             assert (got == want.astype(np.float32)).all(), rec["fen"]
             total += 1
-    assert total == 3400 and feats["block4"][..., 3].sum() == 4 * len(feats["block4"])
+    assert total == 3674 and feats["block4"][..., 3].sum() == 4 * len(feats["block4"])
 
 
 def test_policy_index_of_every_move_equals_get_move_score():

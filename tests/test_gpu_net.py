@@ -41,6 +41,112 @@ def test_f32_tower_within_1e5_of_float64_restatement(blocks, n, perturb):
     assert np.abs(ref_p).max() > 1e-3  # the comparison is not vacuous
 
 
+def game_positions(n, seed, blockers, games=2000):
+    """`n` (mover, opponent) boards drawn with numpy PCG64(seed) from `games` uniformly random games on the GPU — config 1's
+    game file ("4096 positions drawn (seed 4) from the C1 game file, both sides to move")."""
+    p = orc.pos_from_fen(orc.START_FEN_PLAIN)
+    plies, results, boards, moves = link.random_play(games, seed, p.pieces[0], p.pieces[1], blockers, 0, 400)
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, games, size=n)
+    ply = (rng.random(n) * np.maximum(plies[g], 1)).astype(np.int64)
+    xo = boards[g, ply]
+    odd = (ply % 2 == 1)
+    assert 0.3 < odd.mean() < 0.7                           # both sides to move
+    return np.where(odd[:, None], xo[:, ::-1], xo).astype(np.uint64)
+
+
+def note(text):
+    """numbers a green run should leave behind (pytest -q swallows prints): appended to gpurun_out/nn_gate.txt"""
+    import os
+    print(text)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/nn_gate.txt", "a") as f:
+        f.write(text + "\n")
+
+
+def oracle_forward_chunked(conv, bn, lb, blockers, chunk=512):
+    ps, vs = [], []
+    for lo in range(0, len(lb), chunk):
+        p, v = net_oracle.forward(conv, bn, net_oracle.features_from_leaf_boards(lb[lo:lo + chunk], blockers))
+        ps.append(p)
+        vs.append(v)
+    return np.concatenate(ps), np.concatenate(vs)
+
+
+@pytest.mark.parametrize("blocks,net_seed,blockers", [(12, 1, 0), (8, 3, BLOCK4_MASK)])
+def test_f32_tower_within_1e5_on_4096_game_positions(blocks, net_seed, blockers):
+    """The north_star gate at the size SURVEY 8(d) gives it: 4096 positions from real (random-play) games, both sides to
+    move, the bench's own nets (seed 1: 12x128, seed 3: 8x128, model.py:103-114 initialisation)."""
+    conv, bn = model.random_init(blocks, 128, seed=net_seed)
+    lb = game_positions(4096, 4, blockers)
+    logits, values = link.Net(conv, bn).forward(lb, blockers, link.DTYPE_F32)
+    ref_p, ref_v = oracle_forward_chunked(conv, bn, lb, blockers)
+    err_p, err_v = np.abs(logits - ref_p).max(), np.abs(values - ref_v).max()
+    note("f32 tower vs float64 restatement, %dx128 seed %d, 4096 positions: max |dlogit| %.3e, max |dvalue| %.3e "
+         "(max |logit| %.3e)" % (blocks, net_seed, err_p, err_v, np.abs(ref_p).max()))
+    assert err_p <= 1e-5 and err_v <= 1e-5
+    assert np.abs(ref_p).max() > 1e-3 and len(np.unique(lb, axis=0)) > 3000
+
+
+def test_f32_tower_on_a_trained_net_at_4096_positions(tmp_path):
+    """Random-init nets have logits of scale 0.1 (0.2 x He initialisation); a trained net's are one to two orders of
+    magnitude wider, and its batch-norm statistics are no longer (0, 1).  The 12x128 net is trained here the way looper.py
+    trains it — self-play games of the random net on the GPU, then `train.py`'s loop — and the gate is run on the result:
+    1e-5 x max(1, max |logit|), absolute error reported; the 16-bit towers' errors beside it."""
+    import json
+    from ataxxzero_amd import selfplay, training
+    conv, bn = model.random_init(12, 128, seed=1)
+    sp = selfplay.SelfPlay(conv, bn, games=1024, visits=50, dtype="bf16", seed=5, flags=link.FLAG_EVAL_CACHE, select_budget=64)
+    lines = []
+    for _ in range(400):
+        sp.run(100)
+        lines += sp.drain()
+        if len(lines) >= 600:
+            break
+    sp.close()
+    assert len(lines) >= 600
+    games = str(tmp_path / "games.json")
+    with open(games, "w") as f:
+        f.write(b"\n".join(lines).decode() + "\n")
+    old, new = str(tmp_path / "model-001.npy"), str(tmp_path / "model-002.npy")
+    model.save_model(old, conv, bn)
+    training.train([games], old, new, steps=400, minibatch_size=512, log=lambda *a: None)
+    conv2, bn2 = model.load_model(new)
+    assert max(np.abs(np.asarray(b) - (i % 2)).max() for i, b in enumerate(bn2)) > 0.05   # the statistics have moved
+    # half of the boards from the C1 games, half from the self-play games the net was trained on (4 blockers on the board)
+    entries = [json.loads(l) for l in lines[:300]]
+    own = []
+    rng = np.random.default_rng(4)
+    while len(own) < 2048:
+        e = entries[int(rng.integers(0, len(entries)))]
+        ply = int(rng.integers(0, len(e["boards"])))
+        cells = e["boards"][ply]
+        x = sum(1 << (c % 7 + 7 * (6 - c // 7)) for c in range(49) if cells[c] == 1)
+        o = sum(1 << (c % 7 + 7 * (6 - c // 7)) for c in range(49) if cells[c] == 2)
+        own.append([x, o] if ply % 2 == 0 else [o, x])
+    lb = np.concatenate([game_positions(2048, 4, BLOCK4_MASK), np.array(own, dtype=np.uint64)])
+    net = link.Net(conv2, bn2)
+    logits, values = net.forward(lb, BLOCK4_MASK, link.DTYPE_F32)
+    ref_p, ref_v = oracle_forward_chunked(conv2, bn2, lb, BLOCK4_MASK)
+    scale = float(np.abs(ref_p).max())
+    err_p, err_v = np.abs(logits - ref_p).max(), np.abs(values - ref_v).max()
+    report = ["trained 12x128 net (400 steps on %d self-play games), 4096 positions: max |logit| %.3f, max |value| %.3f"
+              % (len(lines), scale, np.abs(ref_v).max()),
+              "  f32 tower vs float64 restatement: max |dlogit| %.3e (%.2e of the scale), max |dvalue| %.3e"
+              % (err_p, err_p / scale, err_v)]
+    note("\n".join(report))
+    report = []
+    assert scale > 0.5                                         # not a near-zero net
+    assert err_p <= 1e-5 * max(1.0, scale) and err_v <= 1e-5
+    for name, dt in (("bf16", link.DTYPE_BF16), ("f16", link.DTYPE_F16)):
+        p, v = net.forward(lb, BLOCK4_MASK, dt)
+        top = (p.reshape(len(p), -1).argmax(1) == ref_p.reshape(len(p), -1).argmax(1)).mean()
+        report.append("  %s tower: max |dlogit| %.3e, max |dvalue| %.3e, same arg-max logit on %.1f %% of the boards"
+                      % (name, np.abs(p - ref_p).max(), np.abs(v - ref_v).max(), 100 * top))
+        assert np.abs(p - ref_p).max() <= (4e-2 if dt == link.DTYPE_BF16 else 5e-3) * max(1.0, scale)
+    note("\n".join(report))
+
+
 @pytest.mark.parametrize("filters,blocks,n", [(64, 3, 29), (256, 2, 10), (256, 4, 7)])
 def test_other_filter_counts(filters, blocks, n):
     """model.Network.FILTERS is a class attribute the reference patches (uai_interface.py:92-93): 64- and 256-filter nets
