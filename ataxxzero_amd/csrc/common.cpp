@@ -29,6 +29,16 @@ extern "C" int azh_set_device(int device)
     return 0;
 }
 
+// "dddd:bb:dd.f" of a device — which physical GPU an ordinal is (two ranks that were handed the same card have
+// different ordinals only if HIP_VISIBLE_DEVICES differs between them: the bus id shows it)
+extern "C" int azh_device_pci_bus_id(int device, char *buf, int cap)
+{
+    if (!buf || cap < 16)
+        return azh_fail(-1, "azh_device_pci_bus_id: buffer of at least 16 bytes needed");
+    AZH_HIP(hipDeviceGetPCIBusId(buf, cap, device));
+    return 0;
+}
+
 int azh_require_device(void)
 {
     int n = azh_device_count();

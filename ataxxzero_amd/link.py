@@ -66,6 +66,7 @@ SIGNATURES = {
     "azh_last_error": (ctypes.c_char_p, []),
     "azh_device_count": (ctypes.c_int, []),
     "azh_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "azh_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     "azh_perft": (ctypes.c_int, [_u64, _u64, _u64, ctypes.c_int, ctypes.c_int, _P(_u64)]),
     "azh_rules_batch": (ctypes.c_int, [ctypes.c_int, _vp, _u64, _vp, _vp, _vp]),
     "azh_makemove_batch": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp]),
@@ -151,6 +152,12 @@ def require_gpu():
         raise AzhError("no MI355X / HIP device visible (azh_device_count = %d: %s); this package has no CPU "
                        "fallback" % (n, load().azh_last_error().decode(errors="replace")))
     return n
+
+
+def pci_bus_id(device):
+    buf = ctypes.create_string_buffer(64)
+    check(load().azh_device_pci_bus_id(int(device), buf, 64))
+    return buf.value.decode()
 
 
 def _ptr(a):

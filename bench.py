@@ -178,7 +178,7 @@ def spread(sp, args, seed):
     return {"mean_ply": float(plies[pick].mean()), "source": SNAPSHOT}
 
 
-def target_leg(conv, bn, args, games=16384, steps=2, warmup=1, flags=0, dtype=None, select_budget=None):
+def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=None, select_budget=None):
     """Another operating point measured the same way as the headline and reported beside it (never as `value`):
     BASELINE.json's north-star point (>= 10k concurrent games on one GPU, 400 sims/move), the headline workload with the
     evaluation cache on (the generator CLI's default), or with the f16 tower."""
@@ -204,6 +204,31 @@ def target_leg(conv, bn, args, games=16384, steps=2, warmup=1, flags=0, dtype=No
                 "parked_share": d.get("parked", 0) / float(max(1, d.get("parked", 0) + d["steps"]))}
     finally:
         sp.close()
+
+
+def config1_leg(games=2000):
+    """BASELINE configs[0] (`generate_games.py --random-play --game-count 2000`) through this repo's drop-in: uniformly
+    random games by the HIP playout kernel, entries built and json-dumped on the host exactly as generate_games.py writes
+    them (to /dev/null here).  Reported beside the reference script's own rate, measured in the build container
+    (26.9 games/s, one core, pure Python)."""
+    from ataxxzero_amd import selfplay
+    selfplay.random_play_entries(64, 1)            # first launch of the kernel
+    t0 = time.perf_counter()
+    entries = selfplay.random_play_entries(games, 20260101)
+    t1 = time.perf_counter()
+    written = plies = 0
+    with open(os.devnull, "w") as sink:
+        for e in entries:
+            if e["result"] is not None:
+                sink.write(json.dumps(e) + "\n")
+                written += 1
+                plies += len(e["moves"])
+    t2 = time.perf_counter()
+    return {"workload": "generate_games.py --random-play --game-count %d (no-blocker start, 400-ply cap)" % games,
+            "games": written, "games_per_s": written / (t2 - t0), "plies_per_s": plies / (t2 - t0),
+            "playout_kernel_and_copy_s": t1 - t0, "host_entries_and_json_s": t2 - t1,
+            "mean_plies": plies / float(max(written, 1)),
+            "reference_script_games_per_s": 26.9, "reference_source": "BASELINE.md §2 (unmodified script, 1 core, this repo's build container)"}
 
 
 def spawn_ranks(n):
@@ -281,6 +306,10 @@ def main():
         return spawn_ranks(args.gpus)
 
     from ataxxzero_amd import distrib
+    # every rank's host threads (its own loop, the HIP runtime's helpers) on a core share of its own, taken before any
+    # of them exists: the host side is all the ranks of a node have in common
+    _, local_rank, _ = distrib.world()
+    cores = distrib.pin_host_threads(local_rank, distrib.local_world())
     group = distrib.Group()
     if group.world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, group.world))
@@ -291,17 +320,21 @@ def main():
         group.barrier()
         units, secs = 1000.0 * (group.rank + 1), 1.0 + group.rank
         total, t_max, rate = distrib.aggregate(group, units, secs)
+        # (AZH_SELFTEST_SAME_CARD: every rank reports one bus id, to rehearse how two ranks on one card show up)
+        bus = "0000:%02x:00.0" % (5 if os.environ.get("AZH_SELFTEST_SAME_CARD") else 5 + group.local_rank)
+        per_rank = distrib.per_rank_report(group, units / secs, 1e3 * secs, distrib.device_for(group.local_rank, 0), bus, cores)
         group.barrier()
         if group.rank == 0:
             print(json.dumps({"metric": "plumbing selftest (no GPU work)", "value": None, "n_gpus": group.world,
-                              "data": "none", "units_total": total, "t_max": t_max, "rate": rate,
+                              "data": "none", "units_total": total, "t_max": t_max, "rate": rate, "per_rank": per_rank,
                               "seeds": [distrib.shard_seed(20260101, r) for r in range(group.world)]}))
         group.close()
         return 0
 
     from ataxxzero_amd import link, model, selfplay
     ndev = link.require_gpu()
-    link.check(link.load().azh_set_device(distrib.device_for(group.local_rank, ndev)))
+    device = distrib.device_for(group.local_rank, ndev)
+    link.check(link.load().azh_set_device(device))
 
     conv, bn = model.random_init(args.blocks, 128, seed=1)
     sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
@@ -314,6 +347,8 @@ def main():
     plies_total = group.reduce(d["plies"], "sum")
     games_total = group.reduce(d["games"], "sum")     # finished games (result 1 or 2), device counter
     written_total = group.reduce(finished, "sum")      # of which written out (games from loaded positions are not)
+    # each rank's own figures, device and cores beside the aggregate (a straggler, or two ranks on one card, must show)
+    per_rank = distrib.per_rank_report(group, d["steps"] / dt, 1e3 * dt / args.steps, device, link.pci_bus_id(device), cores)
 
     if group.rank == 0:
         flops = model.flops_per_eval(args.blocks, 128)
@@ -370,6 +405,7 @@ def main():
                               "bytes_per_step": tree_bytes(d) / float(max(d["steps"], 1)),
                               "levels_per_step": d["levels"] / float(max(d["steps"], 1)),
                               "children_per_step": d["children"] / float(max(d["steps"], 1))},
+            "per_rank": per_rank,
             "counters": d,
         }
         sp.close()
@@ -386,6 +422,8 @@ def main():
                 # the f16 tower on the headline workload: closer to the f32 search than bf16 (profiles/
                 # round2_precision_in_the_loop.json: top-1 100 % / TV 0.02 % vs 98.4 % / 1.7 %); BASELINE names bf16
                 out["with_f16"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2, dtype="f16")
+        if group.world == 1 and not args.no_target_leg:
+            out["config1_random_play"] = config1_leg()
         if group.world == 1 and not args.no_gemm_ceiling:
             out["roofline"]["vendor_gemm_on_this_box"] = vendor_gemm_ceiling()
         if group.world == 1 and not args.no_cpu_baseline:

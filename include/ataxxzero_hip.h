@@ -43,6 +43,9 @@ const char *azh_last_error(void);
 int azh_device_count(void);
 /* select the device used by every later call from this process (one process per GPU) */
 int azh_set_device(int device);
+/* PCI bus id ("0000:05:00.0") of HIP device `device`: bench.py --gpus N prints it per rank, so that two ranks on one card
+ * (or a straggling card) can be told from the aggregate line. */
+int azh_device_pci_bus_id(int device, char *buf, int cap);
 
 /* ------------------------------------------------------------------ rules
  * Replaces cpp/movegen.cpp:10-79 (movegen), cpp/makemove.cpp:56-76 (makemove),

@@ -13,8 +13,8 @@ restates the published semantics of those ops:
       gamma = 1, beta = 0 (not saved by model.save_model: SURVEY.md appendix B, Q1)
   value = tanh(reshape(conv1x1(h), [N,49]) @ fc_w + fc_b)
 
-float64 by default (the 1e-5 gate of the HIP f32 path is checked against this);
-float32 for the bench's cpu_baseline timing.
+float64 by default (the 1e-5 gate of the HIP f32 path is checked against this).  Imported by tests/ and
+__graft_entry__.smoke() only: bench.py's cpu_baseline is tools/cpu_baseline, not this file.
 """
 import numpy as np
 

@@ -76,6 +76,35 @@ def test_bench_py_starts_its_own_ranks_and_aggregates():
     assert out["n_gpus"] == 2 and out["value"] is None
     assert out["units_total"] == 3000.0 and out["t_max"] == 2.0 and out["rate"] == 1500.0
     assert out["seeds"] == [20260101, 20260102]
+    # each rank's own figures beside the aggregate: a straggler shows (rank 1 took twice as long), and so would two ranks
+    # on one card
+    pr = out["per_rank"]
+    assert pr["value"] == [1000.0, 1000.0] and pr["ms_per_step"] == [1000.0, 2000.0]
+    assert pr["ms_per_step_min_max"] == [1000.0, 2000.0] and pr["value_min_max"] == [1000.0, 1000.0]
+    assert pr["device"] == [0, 1] and pr["pci_bus_id"] == ["0000:05:00.0", "0000:06:00.0"]
+    assert pr["ranks_sharing_a_device"] == 0
+    # the ranks' host threads sit on disjoint core shares (when this box has at least two cores to share out)
+    shares = [tuple(int(x) for x in h.split(" ")[0].split("-")) for h in pr["host_cores"]]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert shares[0][1] < shares[1][0]
+
+    env["AZH_SELFTEST_SAME_CARD"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest"],
+                         env=env, capture_output=True, timeout=240)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert json.loads(res.stdout.decode().strip().splitlines()[-1])["per_rank"]["ranks_sharing_a_device"] == 1
+
+
+def test_core_shares_are_disjoint_and_cover_every_rank():
+    sys.path.insert(0, ROOT)
+    from ataxxzero_amd import distrib
+    cores = list(range(3, 3 + 64))
+    shares = [distrib.core_share(r, 8, cores) for r in range(8)]
+    assert all(len(s) == 8 for s in shares) and sorted(sum(shares, [])) == cores
+    assert distrib.core_share(0, 1, cores) == cores                         # one rank keeps everything (the CPU baseline needs it)
+    assert distrib.core_share(5, 8, [0, 1, 2]) == [0, 1, 2]                 # fewer cores than ranks: nobody is starved
+    assert distrib.numbers_to_pci(distrib.pci_to_numbers("0000:f5:00.0")) == "0000:f5:00.0"
+    assert distrib.numbers_to_pci(distrib.pci_to_numbers("garbage")) is None
 
 
 def test_bench_py_eight_ranks_as_the_scaling_run_starts_them():
@@ -94,6 +123,8 @@ def test_bench_py_eight_ranks_as_the_scaling_run_starts_them():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["units_total"] == 1000.0 * 36 and out["t_max"] == 8.0
     assert out["seeds"] == [20260101 + r for r in range(8)]
+    assert out["per_rank"]["device"] == list(range(8)) and len(set(out["per_rank"]["pci_bus_id"])) == 8
+    assert out["per_rank"]["ms_per_step_min_max"] == [1000.0, 8000.0]
     print("8-rank launch, rendezvous and teardown: %.1f s wall" % (time.time() - t0))
 
 

@@ -92,12 +92,22 @@ def test_accelerated_generate_games_cli_appends_and_stops_on_sigterm(tmp_path):
 
 def test_generate_games_random_play_cli(tmp_path):
     path = str(tmp_path / "random.json")
+    t0 = time.time()
     res = subprocess.run([sys.executable, os.path.join(ROOT, "generate_games.py"), "--random-play", "--output-games", path,
-                          "--game-count", "300"], cwd=ROOT, capture_output=True, timeout=240)
+                          "--game-count", "2000"], cwd=ROOT, capture_output=True, timeout=600)   # BASELINE configs[0] verbatim
+    wall = time.time() - t0
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     assert b"Doing random play" in res.stdout and b"Done generating games." in res.stdout
     lines = [l for l in open(path) if l.strip()]
-    assert len(lines) == 300
+    assert len(lines) == 2000
+    rate = [l for l in res.stdout.decode().splitlines() if "Rate:" in l][-1]
+    # beside BASELINE.md §2: the reference script, unmodified, one core of the build container: 74.5 s = 26.9 games/s
+    note = ("config 1 (generate_games.py --random-play --game-count 2000): %s; whole process %.1f s = %.1f games/s; "
+            "reference script 26.9 games/s" % (rate.split("] ", 1)[-1], wall, 2000 / wall))
+    print(note)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config1_rate.txt"), "w") as f:
+        f.write(note + "\n")
     plies = []
     for line in lines[:60]:
         assert '", "' not in line and "], [" in line  # json.dump default separators (generate_games.py:134)
