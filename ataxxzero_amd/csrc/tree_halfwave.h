@@ -1,0 +1,613 @@
+// The tree phase with TWO games per wave, 32 lanes each (included by engine.hip inside namespace azh, after the
+// one-wave-per-game functions whose arithmetic it repeats).
+//
+// Why: a CU holds 32 waves, the chip 8192; beyond that many games the one-wave-per-game launch runs in rounds, and the
+// launch lasts as long as the deepest descent of its last round (16384 games: waves of the second round start 47 us late
+// on average, profiles/round3_tree_stamps.txt).  With 32 lanes per game 16384 descents fit the wave slots at once.
+//
+// Same functions, same reference lines (select_game / backup_game / mark_game above), same results bit for bit:
+//   * every per-game value is an ordinary per-lane value that is equal across the game's 32 lanes; the two games of a
+//     wave take their own paths under the EXEC mask; cross-lane traffic never leaves a game (azh_device.h, namespace hw);
+//   * element j of a node's move list lives in lane j % 32; where the engine/oracle contract fixes the order of an f32
+//     sum (softmax denominator, Dirichlet total) the lane keeps two partial sums — elements with (j / 32) even and odd,
+//     i.e. virtual lanes l and l + 32 of the 64-lane order — and hw::sum_f32 combines them exactly as the 64-lane
+//     butterfly does.  The oracle does not change.
+// Not provided on 32 lanes (the engine keeps one wave per game for them): the arena's flags (AZH_FLAG_PY_POSTERIOR's
+// 833-way softmax, two nets) — arena batches are a thousand games, far from the 8192 where this matters.
+
+// Node holding the evaluation of board (w0, w1), or NONE: the same 64 probe slots as tt_lookup, two per lane.
+__device__ inline u32 tt_lookup_h(const u32 *tt, u32 mask, const Arena &A, u64 w0, u64 w1)
+{
+    const int l = hw::lane();
+    const u32 h = tt_hash(w0, w1, mask);
+    const u32 id0 = tt[(h + (u32)l) & mask], id1 = tt[(h + (u32)l + 32u) & mask];
+    const u64 empties = (u64)hw::ballot(id0 == NONE) | ((u64)hw::ballot(id1 == NONE) << 32);
+    const u64 before = empties ? (empties & (0ULL - empties)) - 1ULL : ~0ULL;  // slots ahead of the first empty one
+    bool m0 = false, m1 = false;
+    if (((before >> l) & 1ULL) && id0 != NONE) {
+        const ulonglong2 b = A.nb[id0];
+        m0 = b.x == w0 && b.y == w1;
+    }
+    if (((before >> (l + 32)) & 1ULL) && id1 != NONE) {
+        const ulonglong2 b = A.nb[id1];
+        m1 = b.x == w0 && b.y == w1;
+    }
+    const u64 hits = (u64)hw::ballot(m0) | ((u64)hw::ballot(m1) << 32);
+    if (!hits)
+        return NONE;
+    const int first = __ffsll((long long)hits) - 1;
+    return (u32)hw::read_lane((int)(first < 32 ? id0 : id1), first & 31);
+}
+
+// select_game on 32 lanes.  `s`: the game's state after backup / mark (equal in the game's lanes).
+//
+// Written for a small register footprint — two games share a wave, so what select_game keeps in scalar registers is
+// per-lane data here, and 16384 resident games need 8 waves per SIMD, i.e. at most 64 vector registers: the state is
+// stored at once (what backup and mark changed) and only the fields select itself changes are stored again at the end;
+// the node and edge counts are re-read at the expansion, beside the loads the expansion waits for anyway; of the arena
+// only the edge base is kept as a pointer; the leaf board is stored where it is computed.
+template <bool STAMP = false>
+__device__ inline int select_game_h(const EngineParams &P, int g, const azh_game_state &s, u16 *s_moves, u64 *st = nullptr)
+{
+    constexpr int HL = 32;
+    const int l = hw::lane();
+    const u32 slot = (u32)s.arena * (u32)P.G + (u32)g;
+    uint4 *const ed = P.edge + (size_t)slot * P.edge_cap;
+    azh_game_state *const gs = P.gs + g;
+    if (l == 0)
+        *gs = s;
+
+    int kind = AZH_LEAF_NONE, leaf_node = 0, depth = 0;
+    // bit 0: an MCTS step begins, 1: evaluation found in the tree, 2: edge arena overflow
+    u32 flags = 0, st_levels = 0, st_children = 0, st_newmoves = 0;
+
+    if (s.phase >= 2) {
+        kind = AZH_LEAF_NONE;  // the move is due (its re-root runs after this select) or the slot is idle
+        if (l == 0)
+            P.leaf_board[g] = make_ulonglong2(0ull, 0ull);
+    } else if (s.phase == 0) {
+        kind = AZH_LEAF_ROOT;  // the root's priors are (re)computed with noise (:380-383, :485-490)
+        const ulonglong2 w = P.node_board[(size_t)slot * P.node_cap];
+        const Board b = unpack_board(w.x, w.y);
+        if (l == 0)
+            P.leaf_board[g] = b.turn ? make_ulonglong2(b.o, b.x) : make_ulonglong2(b.x, b.o);
+    } else {
+        const bool resume = s.leaf_kind == AZH_LEAF_DESCENT;
+        flags = resume ? 0u : 1u;
+        u32 node = resume ? (u32)s.leaf_node : 0u;
+        depth = resume ? s.path_len : 0;
+        u32 kid;
+        {
+            const uint4 rinfo = P.node_info[(size_t)slot * P.node_cap + node];
+            kid = pack_kid(rinfo.x, rinfo.y & 0xFFFFu, (rinfo.y >> 16) != 0u);
+        }
+        int levels_done = 0;
+        bool have_n = !resume;
+        u32 n_node = (u32)s.root_visits;
+        // the path entries of this launch: lane k keeps entries k and k + 32, stored together afterwards (every 64 levels
+        // when there is no budget)
+        u32 path_buf0 = 0, path_buf1 = 0;
+        int path_base = depth;
+        auto path_of = [&]() { return P.path + (size_t)g * P.path_cap; };
+        auto push_path = [&](u32 eidx) {
+            const int k = depth - path_base;
+            if (l == (k & 31)) {
+                if (k < HL) path_buf0 = eidx;
+                else path_buf1 = eidx;
+            }
+            depth++;
+            if (depth - path_base == 2 * HL) {
+                int *path = path_of();
+                path[path_base + l] = (int)path_buf0;
+                path[path_base + HL + l] = (int)path_buf1;
+                path_base = depth;
+            }
+        };
+        uint4 ea0 = fresh_edge(0u), ea1 = fresh_edge(0u);
+        bool cur_loaded = false;
+        auto load_children = [&](u32 k, uint4 &r0, uint4 &r1) {
+            const int cnt = kid_count(k);
+            const uint4 *f = ed + kid_first(k) + (u32)l;
+            r0 = fresh_edge(0u);
+            r1 = fresh_edge(0u);
+            if (l < cnt)
+                r0 = f[0];
+            if (l + HL < cnt)
+                r1 = f[HL];
+        };
+        u32 sel_eidx = 0;
+        bool expand = false;
+        for (;;) {
+            if (P.select_budget != 0 && levels_done == P.select_budget) {
+                kind = AZH_LEAF_DESCENT;
+                leaf_node = (int)node;
+                break;
+            }
+            levels_done++;
+            const int M = kid_count(kid);
+            const u32 first = kid_first(kid);
+            if (kid_finished(kid) || M == 0) {
+                kind = AZH_LEAF_TERMINAL;
+                leaf_node = (int)node;
+                break;
+            }
+            st_levels += 1;
+            st_children += (u32)M;
+            u32 zsel, wsel, eidx;
+            if (M <= 2 * HL) {
+                // fast path: up to 64 children, two records per lane; the same arithmetic as select_game's
+                if (!cur_loaded)
+                    load_children(kid, ea0, ea1);
+                cur_loaded = false;
+                const uint4 e0 = ea0, e1 = ea1;
+                uint4 en0 = fresh_edge(0u), en1 = fresh_edge(0u);
+                const bool live0 = l < M, live1 = l + HL < M;
+                // the remembered child, requested before anything is scored
+                const u32 unv0 = hw::ballot(live0 && edge_child(e0) == ENONE);
+                const u32 unv1 = hw::ballot(live1 && edge_child(e1) == ENONE);
+                int u0 = -1, pv = -1, pred = -1;
+                if (unv0 | unv1) {
+                    u0 = unv0 ? __ffs((int)unv0) - 1 : HL + __ffs((int)unv1) - 1;
+                    const u32 hint = (u32)hw::read_lane((int)(u0 < HL ? e0.w : e1.w), u0 & 31);
+                    if ((hint >> 31) && (int)(hint & 0xFFu) < M) {
+                        pv = (int)(hint & 0xFFu);
+                        const u32 pz = (u32)hw::read_lane((int)(pv < HL ? e0.z : e1.z), pv & 31);
+                        const u32 pk = (u32)hw::read_lane((int)(pv < HL ? e0.w : e1.w), pv & 31);
+                        if ((pz >> 16) != ENONE && !kid_finished(pk) && kid_count(pk) > 0 && kid_count(pk) <= 2 * HL) {
+                            load_children(pk, en0, en1);
+                            pred = pv;
+                        }
+                    }
+                }
+                const u32 n0 = edge_visits(e0), n1 = edge_visits(e1);
+                const u32 ntot1 = have_n ? n_node : hw::sum_u32(n0 + n1);
+                const float sq1 = sqrtf((float)(1u + ntot1));
+                u32 bits0, bits1;
+                bool valid0, valid1;
+                {
+                    const float prior = u2f(e0.x);
+                    const float W = u2f(e0.y);
+                    const float q = n0 ? W / (float)n0 : 0.0f;
+                    const float u = (sq1 / (1.0f + (float)n0)) * (P.c_puct * prior);
+                    const float score = u + q;
+                    valid0 = live0 && score >= 0.0f;
+                    bits0 = valid0 ? f2u(score + 0.0f) : 0u;
+                }
+                {
+                    const float prior = u2f(e1.x);
+                    const float W = u2f(e1.y);
+                    const float q = n1 ? W / (float)n1 : 0.0f;
+                    const float u = (sq1 / (1.0f + (float)n1)) * (P.c_puct * prior);
+                    const float score = u + q;
+                    valid1 = live1 && score >= 0.0f;
+                    bits1 = valid1 ? f2u(score + 0.0f) : 0u;
+                }
+                const u32 top = hw::max_u32(bits0 > bits1 ? bits0 : bits1);
+                const u32 cand0 = hw::ballot(valid0 && bits0 == top);
+                const u32 cand1 = hw::ballot(valid1 && bits1 == top);
+                int bj = 0;
+                if (P.flags & AZH_FLAG_TIE_FIRST) {
+                    if (cand0)
+                        bj = __ffs((int)cand0) - 1;
+                    else if (cand1)
+                        bj = HL + __ffs((int)cand1) - 1;
+                } else {
+                    if (cand1)
+                        bj = HL + 31 - __clz((int)cand1);
+                    else if (cand0)
+                        bj = 31 - __clz((int)cand0);
+                }
+                eidx = first + (u32)bj;
+                zsel = (u32)hw::read_lane((int)(bj < HL ? e0.z : e1.z), bj & 31);
+                wsel = (u32)hw::read_lane((int)(bj < HL ? e0.w : e1.w), bj & 31);
+                if ((zsel >> 16) != ENONE) {
+                    if (u0 >= 0 && bj != pv && l == 0)
+                        reinterpret_cast<u32 *>(ed + first + (u32)u0)[3] = 0x80000000u | (u32)bj;
+                    if (pred == bj) {
+                        ea0 = en0;
+                        ea1 = en1;
+                        cur_loaded = true;
+                    }
+                }
+            } else {
+                // general path: 65..256 children in chunks of 128 (four records per lane), a running 64-bit (score, index)
+                // key as in select_game; a second chunk (more than 128 moves: rare) costs a second round trip
+                u32 ntot = n_node;
+                if (!have_n) {   // a resumed descent does not know the node's N: sum the children's visits first
+                    u32 nsum = 0;
+                    for (int j = l; j < M; j += HL)
+                        nsum += reinterpret_cast<const u32 *>(ed + first + (u32)j)[2] & 0xFFFFu;
+                    ntot = hw::sum_u32(nsum);
+                }
+                const float sq = sqrtf((float)(1u + ntot));
+                const u32 tie_flip = (P.flags & AZH_FLAG_TIE_FIRST) ? 0xFFFFFFFFu : 0u;
+                u64 key = 0;
+                u32 mine = ENONE << 16, mkid = 0u;
+                for (int base = 0; base < M; base += 4 * HL) {
+                    uint4 ev[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int j = base + l + HL * k;
+                        ev[k] = fresh_edge(0u);
+                        if (j < M)
+                            ev[k] = ed[first + (u32)j];
+                    }
+                    if (base == 0) {
+                        mine = ev[0].z;   // key 0 (no valid score anywhere) selects edge 0 = lane 0's first record
+                        mkid = ev[0].w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int j = base + l + HL * k;
+                        if (j < M) {
+                            const float prior = u2f(ev[k].x);
+                            const u32 n = edge_visits(ev[k]);
+                            const float W = u2f(ev[k].y);
+                            const float q = n ? W / (float)n : 0.0f;
+                            const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
+                            const float score = u + q;
+                            const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)((u32)j ^ tie_flip) : 0ull;
+                            if (kj > key) {
+                                key = kj;
+                                mine = ev[k].z;
+                                mkid = ev[k].w;
+                            }
+                        }
+                    }
+                }
+                key = hw::max_u64(key);
+                const int bj = key ? (int)((u32)key ^ tie_flip) : 0;
+                eidx = first + (u32)bj;
+                zsel = (u32)hw::read_lane((int)mine, bj & 31);
+                wsel = (u32)hw::read_lane((int)mkid, bj & 31);
+                ea0 = fresh_edge(0u);   // (nothing is requested early on this path: the buffers are dead here)
+                ea1 = fresh_edge(0u);
+                cur_loaded = false;
+            }
+            push_path(eidx);
+            if ((zsel >> 16) != ENONE) {
+                node = zsel >> 16;
+                kid = wsel;
+                n_node = (zsel & 0xFFFFu) - 1u;
+                have_n = true;
+                continue;
+            }
+            sel_eidx = eidx;
+            expand = true;
+            break;
+        }
+        if (expand) {
+            // expand (:429-439)
+            if constexpr (STAMP) st[4] = tree_stamp();
+            const u32 eidx = sel_eidx;
+            const size_t nbase = (size_t)slot * P.node_cap, ebase = (size_t)slot * P.edge_cap;
+            const u32 mv = P.edge_move[ebase + eidx];
+            const ulonglong2 pw = P.node_board[nbase + node];
+            const int2 counts = *reinterpret_cast<const int2 *>(&gs->n_nodes);   // (n_nodes, n_edges): not kept over the descent
+            const Board cb = make_move(unpack_board(pw.x, pw.y), (int)(mv & 0xFF), (int)(mv >> 8));
+            int res2;
+            const int M2 = hw::movegen(cb, P.blockers, s_moves, &res2);
+            hw::sync();
+            if (counts.x >= P.node_cap || (res2 == 0 && (counts.y + M2 > P.edge_cap || M2 > 255))) {
+                flags |= 4u;
+                kind = AZH_LEAF_NONE;
+                leaf_node = 0;
+                depth = 0;
+                path_base = 0;
+                if (l == 0)
+                    P.leaf_board[g] = make_ulonglong2(0ull, 0ull);
+            } else {
+                const u32 cid = (u32)counts.x;
+                const u32 nf = (u32)counts.y;
+                u32 known = NONE;
+                if ((P.flags & AZH_FLAG_EVAL_CACHE) && res2 == 0) {
+                    Arena A = arena_of(P, s.arena, g);
+                    known = tt_lookup_h(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, A, pack_word0(cb), cb.o);
+                }
+                int added = 0;
+                if (res2 != 0) {
+                    float tv = res2 == 1 ? 1.0f : -1.0f;
+                    if (cb.turn == 1)
+                        tv = -tv;
+                    if (l == 0)
+                        P.node_info[nbase + cid] = make_uint4(0u, (u32)res2 << 16, 0u, f2u(tv));
+                    kind = AZH_LEAF_TERMINAL;
+                } else if (known != NONE) {
+                    // same position, same moves in the same order: take the priors and the value, no evaluation
+                    const uint4 kinfo = P.node_info[nbase + known];
+                    for (int j = l; j < M2; j += HL) {
+                        ed[nf + j] = fresh_edge(ed[kinfo.x + j].x);
+                        P.edge_move[ebase + nf + j] = s_moves[j];
+                    }
+                    added = M2;
+                    if (l == 0)
+                        P.node_info[nbase + cid] = make_uint4(nf, (u32)M2, 0u, kinfo.w);
+                    kind = AZH_LEAF_TERMINAL;  // "value known": backed up from node_info.w like a finished position
+                    flags |= 2u;
+                    st_newmoves = (u32)M2;
+                } else {
+                    for (int j = l; j < M2; j += HL) {
+                        ed[nf + j] = fresh_edge(0u);
+                        P.edge_move[ebase + nf + j] = s_moves[j];
+                    }
+                    added = M2;
+                    if (l == 0)
+                        P.node_info[nbase + cid] = make_uint4(nf, (u32)M2, 0u, 0u);
+                    kind = AZH_LEAF_EVAL;
+                    st_newmoves = (u32)M2;
+                }
+                if (l == 0) {
+                    P.node_board[nbase + cid] = make_ulonglong2(pack_word0(cb), cb.o);
+                    // the edge gets its child and the child's range
+                    reinterpret_cast<uint2 *>(ed + eidx)[1] =
+                        make_uint2(cid << 16, res2 != 0 ? pack_kid(0u, 0u, 1u) : pack_kid(nf, (u32)M2, 0u));
+                    *reinterpret_cast<int2 *>(&gs->n_nodes) = make_int2(counts.x + 1, counts.y + added);
+                    P.leaf_board[g] = cb.turn ? make_ulonglong2(cb.o, cb.x) : make_ulonglong2(cb.x, cb.o);
+                }
+                leaf_node = (int)cid;
+            }
+        } else if (l == 0) {
+            P.leaf_board[g] = make_ulonglong2(0ull, 0ull);
+        }
+        // the path entries of this launch (none after an overflow: depth is 0 then)
+        const int left = depth - path_base;
+        if (l < left)
+            path_of()[path_base + l] = (int)path_buf0;
+        if (l + HL < left)
+            path_of()[path_base + HL + l] = (int)path_buf1;
+    }
+
+    if constexpr (STAMP) {
+        st[5] = tree_stamp();
+        if (st[4] == 0)
+            st[4] = st[5];
+        st[8] = st_levels;
+        st[9] = st_children;
+    }
+    const int need = (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) ? 1 : 0;
+    if (l == 0) {
+        gs->leaf_kind = kind;
+        gs->leaf_node = leaf_node;
+        gs->path_len = depth;
+        P.need_eval[g] = need;
+        if (flags & 4u)
+            P.force[g] = 1;
+    }
+    {   // counters: lane k owns counter k
+        const u32 inc = l == AZH_STAT_STEPS ? (flags & 1u)
+                      : l == AZH_STAT_NN_EVALS ? (u32)need
+                      : l == AZH_STAT_LEVELS ? st_levels
+                      : l == AZH_STAT_CHILDREN ? st_children
+                      : l == AZH_STAT_NEW_MOVES ? st_newmoves
+                      : l == AZH_STAT_EDGE_OVERFLOW ? (flags >> 2) & 1u
+                      : l == AZH_STAT_CACHE_HITS ? (flags >> 1) & 1u
+                      : l == AZH_STAT_PARKED ? (u32)(kind == AZH_LEAF_DESCENT) : 0u;
+        if (l < NSTAT)
+            add_stat(P, g, l, (u64)inc);
+    }
+    return need;
+}
+
+// backup_game on 32 lanes (cpp/self_play_client.cpp:204-271 priors + noise, :449-459 backup).
+__device__ inline void backup_game_h(const EngineParams &P, int g, azh_game_state &s)
+{
+    constexpr int HL = 32, R = MAX_MOVES / HL;  // 8 elements per lane; element j = l + 32 r: virtual lane l + 32 (r & 1)
+    const int l = hw::lane();
+    const int kind = s.leaf_kind;
+    if (kind == AZH_LEAF_NONE || kind == AZH_LEAF_DESCENT)
+        return;
+    Arena A = arena_of(P, s.arena, g);
+
+    if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) {
+        const uint4 info = A.ni[s.leaf_node];
+        const u32 first = info.x;
+        const int M = (int)(info.y & 0xFFFFu);
+        const float *row = P.logits + (size_t)g * AZH_POLICY_SIZE;
+        float ex[R];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int j = l + HL * r;
+            ex[r] = -INFINITY;
+            if (j < M) {
+                ex[r] = row[policy_index(A.em[first + j])];
+                if (ex[r] > mx)
+                    mx = ex[r];
+            }
+        }
+        mx = hw::max_f32(mx);
+        float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int j = l + HL * r;
+            const float lg = ex[r];
+            ex[r] = 0.0f;
+            if (j < M) {
+                ex[r] = det_expf(lg - mx);
+                if (r & 1) p1 = p1 + ex[r];
+                else p0 = p0 + ex[r];
+            }
+        }
+        const float S = hw::sum_f32(p0, p1);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            ex[r] = S > 0.0f ? ex[r] / S : ex[r];
+        if (kind == AZH_LEAF_ROOT && P.noise_w > 0.0f) {
+            float gm[R];
+            float g0 = 0.0f, g1 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int j = l + HL * r;
+                gm[r] = 0.0f;
+                if (j < M) {
+                    gm[r] = det_gamma(P.alpha, P.k0, P.k1, s.uid, (u32)s.ply, (u32)j);
+                    if (r & 1) g1 = g1 + gm[r];
+                    else g0 = g0 + gm[r];
+                }
+            }
+            const float T = hw::sum_f32(g0, g1);
+            const float w = P.noise_w, omw = 1.0f - w;
+            if (T > 0.0f) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float d = gm[r] / T;
+                    const float t1 = w * d;
+                    const float t2 = omw * ex[r];
+                    ex[r] = t1 + t2;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int j = l + HL * r;
+            if (j < M)
+                reinterpret_cast<u32 *>(&A.ed[first + j])[0] = f2u(ex[r]);
+        }
+    }
+
+    if ((P.flags & AZH_FLAG_EVAL_CACHE) && kind == AZH_LEAF_EVAL) {
+        if (l == 0) {
+            reinterpret_cast<u32 *>(&A.ni[s.leaf_node])[3] = f2u(P.values[g]);
+            const ulonglong2 b = A.nb[s.leaf_node];
+            tt_insert(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, b.x, b.y, (u32)s.leaf_node);
+        }
+    }
+    if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_TERMINAL) {
+        const float v = kind == AZH_LEAF_EVAL ? P.values[g] : u2f(A.ni[s.leaf_node].w);
+        const float sc0 = (v + 1.0f) * 0.5f;
+        const float fa = 1.0f - sc0, fb = 1.0f - fa, fc = 1.0f - fb;
+        const int *path = P.path + (size_t)g * P.path_cap;
+        for (int i = l; i < s.path_len; i += HL) {
+            const int flips = s.path_len - i;
+            const float val = flips == 1 ? fa : ((flips & 1) ? fc : fb);
+            u32 *e = reinterpret_cast<u32 *>(&A.ed[path[i]]);
+            e[1] = f2u(u2f(e[1]) + val);
+            e[2] += 1u;
+        }
+        if (s.path_len > 0)
+            s.root_visits += 1;
+    }
+    if (kind == AZH_LEAF_ROOT)
+        s.phase = 1;
+    s.leaf_kind = AZH_LEAF_NONE;
+}
+
+__device__ inline void mark_game_h(const EngineParams &P, int g, azh_game_state &s, int forced)
+{
+    if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= P.visits || forced != 0)) {
+        s.phase = 2;
+        if (hw::lane() == 0)
+            P.adv_list[atomicAdd(P.adv_count, 1)] = g;
+    }
+}
+
+// the step-wise API's kernels: two games per 64-thread workgroup
+__global__ __launch_bounds__(WAVE) void k_select_h(EngineParams P)
+{
+    __shared__ u16 s_moves[2][MAX_MOVES];
+    const int g = 2 * (int)blockIdx.x + hw::half();
+    if (g < P.G) {
+        azh_game_state s = P.gs[g];
+        select_game_h(P, g, s, s_moves[hw::half()]);
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void k_backup_h(EngineParams P)
+{
+    const int g = 2 * (int)blockIdx.x + hw::half();
+    if (g < P.G) {
+        azh_game_state s = P.gs[g];
+        const int kind = s.leaf_kind;
+        backup_game_h(P, g, s);
+        if (kind != AZH_LEAF_NONE && kind != AZH_LEAF_DESCENT && hw::lane() == 0)
+            P.gs[g] = s;
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void k_mark_h(EngineParams P)
+{
+    const int g = 2 * (int)blockIdx.x + hw::half();
+    if (g < P.G) {
+        azh_game_state s = P.gs[g];
+        const int phase = s.phase;
+        mark_game_h(P, g, s, P.force[g]);
+        if (s.phase != phase && hw::lane() == 0)
+            P.gs[g] = s;
+    }
+}
+
+// k_tree with two games per wave: TREE_WAVES waves = 2 * TREE_WAVES games per workgroup; the leaf-list compaction by
+// the last workgroup is k_tree's (compact_leaves), with one net.
+template <bool STAMP, int TREE_WAVES>
+__global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree_h(EngineParams P, int mode)
+{
+    constexpr int GAMES = 2 * TREE_WAVES;
+    __shared__ u16 s_moves[GAMES][MAX_MOVES];
+    __shared__ int s_cnt[2 * TREE_WAVES];
+    __shared__ int s_need[GAMES];
+    __shared__ int s_last;
+    static_assert(32 % GAMES == 0, "a workgroup's need bits must lie in one word of the mask");
+    const int slot = (int)(threadIdx.x >> 5);
+    const int g = (int)blockIdx.x * GAMES + slot;
+    u64 st[TREE_STAMPS] = {};
+    int need = 0;
+    if constexpr (STAMP) st[0] = tree_stamp();
+    if (g < P.G) {
+        azh_game_state s = P.gs[g];
+        const int forced = P.force[g];
+        if constexpr (STAMP) st[1] = tree_stamp();
+        if (mode & 1) {
+            backup_game_h(P, g, s);
+            if constexpr (STAMP) st[2] = tree_stamp();
+            mark_game_h(P, g, s, forced);
+        }
+        if constexpr (STAMP) {
+            st[3] = tree_stamp();
+            if (!(mode & 1)) st[2] = st[3];
+        }
+        if (mode & 2)
+            need = select_game_h<STAMP>(P, g, s, s_moves[slot], st);
+        else if (hw::lane() == 0)
+            P.gs[g] = s;
+    }
+    if (!(mode & 2))
+        return;
+    if (hw::lane() == 0)
+        s_need[slot] = need;
+    if constexpr (STAMP) st[6] = tree_stamp();
+    __syncthreads();
+    if constexpr (STAMP) {
+        st[7] = tree_stamp();
+        if (g < P.G && hw::lane() < TREE_STAMPS) {
+            u64 v = st[0];
+#pragma unroll
+            for (int k = 1; k < TREE_STAMPS; k++)
+                v = hw::lane() == k ? st[k] : v;
+            P.stamps[(size_t)g * TREE_STAMPS + hw::lane()] = v;
+        }
+    }
+    if (threadIdx.x == 0) {
+        u32 m1 = 0;
+#pragma unroll
+        for (int k = 0; k < GAMES; k++)
+            m1 |= (u32)(s_need[k] != 0) << k;
+        const int g0 = (int)blockIdx.x * GAMES;
+        u32 seen = 0;
+        if (m1)
+            seen |= __hip_atomic_fetch_or(&P.need_mask[g0 >> 5], m1 << (g0 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" : : "v"(seen) : "memory");   // the OR has been performed before the ticket is drawn
+        const int shard = (int)(blockIdx.x % TICKET_SHARDS);
+        const int in_shard = ((int)gridDim.x - 1 - shard) / TICKET_SHARDS + 1;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&P.tree_done[shard * TICKET_STRIDE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            __hip_atomic_store(&P.tree_done[shard * TICKET_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int shards = min((int)gridDim.x, TICKET_SHARDS);
+            last = __hip_atomic_fetch_add(&P.tree_done[TICKET_SHARDS * TICKET_STRIDE], 1, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (s_last)
+        compact_leaves<TREE_WAVES>(P, 0, s_cnt);
+}

@@ -94,7 +94,7 @@ def test_f32_tower_on_a_trained_net_at_4096_positions(tmp_path):
     trains it — self-play games of the random net on the GPU, then `train.py`'s loop — and the gate is run on the result:
     1e-5 x max(1, max |logit|), absolute error reported; the 16-bit towers' errors beside it."""
     import json
-    from ataxxzero_amd import selfplay, training
+    from ataxxzero_amd import selfplay
     conv, bn = model.random_init(12, 128, seed=1)
     sp = selfplay.SelfPlay(conv, bn, games=1024, visits=50, dtype="bf16", seed=5, flags=link.FLAG_EVAL_CACHE, select_budget=64)
     lines = []
@@ -110,7 +110,14 @@ def test_f32_tower_on_a_trained_net_at_4096_positions(tmp_path):
         f.write(b"\n".join(lines).decode() + "\n")
     old, new = str(tmp_path / "model-001.npy"), str(tmp_path / "model-002.npy")
     model.save_model(old, conv, bn)
-    training.train([games], old, new, steps=400, minibatch_size=512, log=lambda *a: None)
+    # (train.py in a process of its own, as looper.py runs it: torch's HIP runtime and this library's do not share a process)
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--steps", "400", "--games", games, "--old-path", old,
+                          "--new-path", new], cwd=root, capture_output=True, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
     conv2, bn2 = model.load_model(new)
     assert max(np.abs(np.asarray(b) - (i % 2)).max() for i, b in enumerate(bn2)) > 0.05   # the statistics have moved
     # half of the boards from the C1 games, half from the self-play games the net was trained on (4 blockers on the board)
