@@ -46,16 +46,36 @@ __device__ inline u32 tt_lookup_h(const u32 *tt, u32 mask, const Arena &A, u64 w
 // stored at once (what backup and mark changed) and only the fields select itself changes are stored again at the end;
 // the node and edge counts are re-read at the expansion, beside the loads the expansion waits for anyway; of the arena
 // only the edge base is kept as a pointer; the leaf board is stored where it is computed.
+// The fields of azh_game_state the tree phase reads (the node / edge counts are read where an expansion needs them, ply
+// and uid where a root's noise is drawn): six registers per lane instead of ten.
+struct HState {
+    int phase, arena, root_visits, leaf_kind, leaf_node, path_len;
+};
+
+__device__ inline HState load_hstate(const azh_game_state *gs)
+{
+    HState h;
+    h.phase = gs->phase;
+    h.arena = gs->arena;
+    h.root_visits = gs->root_visits;
+    h.leaf_kind = gs->leaf_kind;
+    h.leaf_node = gs->leaf_node;
+    h.path_len = gs->path_len;
+    return h;
+}
+
 template <bool STAMP = false>
-__device__ inline int select_game_h(const EngineParams &P, int g, const azh_game_state &s, u16 *s_moves, u64 *st = nullptr)
+__device__ inline int select_game_h(const EngineParams &P, int g, const HState &s, u16 *s_moves, u64 *st = nullptr)
 {
     constexpr int HL = 32;
     const int l = hw::lane();
     const u32 slot = (u32)s.arena * (u32)P.G + (u32)g;
     uint4 *const ed = P.edge + (size_t)slot * P.edge_cap;
     azh_game_state *const gs = P.gs + g;
-    if (l == 0)
-        *gs = s;
+    if (l == 0) {   // what backup and mark may have changed (select's own fields follow at the end)
+        gs->phase = s.phase;
+        gs->root_visits = s.root_visits;
+    }
 
     int kind = AZH_LEAF_NONE, leaf_node = 0, depth = 0;
     // bit 0: an MCTS step begins, 1: evaluation found in the tree, 2: edge arena overflow
@@ -388,21 +408,26 @@ __device__ inline int select_game_h(const EngineParams &P, int g, const azh_game
     return need;
 }
 
-// backup_game on 32 lanes (cpp/self_play_client.cpp:204-271 priors + noise, :449-459 backup).
-__device__ inline void backup_game_h(const EngineParams &P, int g, azh_game_state &s)
+// backup_game on 32 lanes (cpp/self_play_client.cpp:204-271 priors + noise, :449-459 backup).  `scratch`: 256 floats of LDS
+// of this game's own (the root's gamma draws wait there for their total: eight interleaved Philox chains in registers cost
+// the whole kernel a wave per SIMD).
+__device__ inline void backup_game_h(const EngineParams &P, int g, HState &s, float *scratch)
 {
     constexpr int HL = 32, R = MAX_MOVES / HL;  // 8 elements per lane; element j = l + 32 r: virtual lane l + 32 (r & 1)
     const int l = hw::lane();
     const int kind = s.leaf_kind;
     if (kind == AZH_LEAF_NONE || kind == AZH_LEAF_DESCENT)
         return;
-    Arena A = arena_of(P, s.arena, g);
+    const u32 slot = (u32)s.arena * (u32)P.G + (u32)g;
+    uint4 *const ed = P.edge + (size_t)slot * P.edge_cap;
+    uint4 *const ni = P.node_info + (size_t)slot * P.node_cap;
 
     if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) {
-        const uint4 info = A.ni[s.leaf_node];
+        const uint4 info = ni[s.leaf_node];
         const u32 first = info.x;
         const int M = (int)(info.y & 0xFFFFu);
         const float *row = P.logits + (size_t)g * AZH_POLICY_SIZE;
+        const u16 *em = P.edge_move + (size_t)slot * P.edge_cap + first;
         float ex[R];
         float mx = -INFINITY;
 #pragma unroll
@@ -410,7 +435,7 @@ __device__ inline void backup_game_h(const EngineParams &P, int g, azh_game_stat
             const int j = l + HL * r;
             ex[r] = -INFINITY;
             if (j < M) {
-                ex[r] = row[policy_index(A.em[first + j])];
+                ex[r] = row[policy_index(em[j])];
                 if (ex[r] > mx)
                     mx = ex[r];
             }
@@ -433,16 +458,17 @@ __device__ inline void backup_game_h(const EngineParams &P, int g, azh_game_stat
         for (int r = 0; r < R; r++)
             ex[r] = S > 0.0f ? ex[r] / S : ex[r];
         if (kind == AZH_LEAF_ROOT && P.noise_w > 0.0f) {
-            float gm[R];
+            const u32 uid = P.gs[g].uid, ply = (u32)P.gs[g].ply;
             float g0 = 0.0f, g1 = 0.0f;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int j = l + HL * r;
-                gm[r] = 0.0f;
-                if (j < M) {
-                    gm[r] = det_gamma(P.alpha, P.k0, P.k1, s.uid, (u32)s.ply, (u32)j);
-                    if (r & 1) g1 = g1 + gm[r];
-                    else g0 = g0 + gm[r];
+#pragma unroll 1
+            for (int j = l; j < M; j += 2 * HL) {   // one draw at a time; this lane's virtual lanes in turn, rounds in order
+                const float a = det_gamma(P.alpha, P.k0, P.k1, uid, ply, (u32)j);
+                scratch[j] = a;
+                g0 = g0 + a;
+                if (j + HL < M) {
+                    const float b = det_gamma(P.alpha, P.k0, P.k1, uid, ply, (u32)(j + HL));
+                    scratch[j + HL] = b;
+                    g1 = g1 + b;
                 }
             }
             const float T = hw::sum_f32(g0, g1);
@@ -450,7 +476,8 @@ __device__ inline void backup_game_h(const EngineParams &P, int g, azh_game_stat
             if (T > 0.0f) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const float d = gm[r] / T;
+                    const int j = l + HL * r;
+                    const float d = (j < M ? scratch[j] : 0.0f) / T;   // (this lane's own stores)
                     const float t1 = w * d;
                     const float t2 = omw * ex[r];
                     ex[r] = t1 + t2;
@@ -461,26 +488,26 @@ __device__ inline void backup_game_h(const EngineParams &P, int g, azh_game_stat
         for (int r = 0; r < R; r++) {
             const int j = l + HL * r;
             if (j < M)
-                reinterpret_cast<u32 *>(&A.ed[first + j])[0] = f2u(ex[r]);
+                reinterpret_cast<u32 *>(ed + first + j)[0] = f2u(ex[r]);
         }
     }
 
     if ((P.flags & AZH_FLAG_EVAL_CACHE) && kind == AZH_LEAF_EVAL) {
         if (l == 0) {
-            reinterpret_cast<u32 *>(&A.ni[s.leaf_node])[3] = f2u(P.values[g]);
-            const ulonglong2 b = A.nb[s.leaf_node];
+            reinterpret_cast<u32 *>(ni + s.leaf_node)[3] = f2u(P.values[g]);
+            const ulonglong2 b = P.node_board[(size_t)slot * P.node_cap + s.leaf_node];
             tt_insert(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, b.x, b.y, (u32)s.leaf_node);
         }
     }
     if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_TERMINAL) {
-        const float v = kind == AZH_LEAF_EVAL ? P.values[g] : u2f(A.ni[s.leaf_node].w);
+        const float v = kind == AZH_LEAF_EVAL ? P.values[g] : u2f(ni[s.leaf_node].w);
         const float sc0 = (v + 1.0f) * 0.5f;
         const float fa = 1.0f - sc0, fb = 1.0f - fa, fc = 1.0f - fb;
         const int *path = P.path + (size_t)g * P.path_cap;
         for (int i = l; i < s.path_len; i += HL) {
             const int flips = s.path_len - i;
             const float val = flips == 1 ? fa : ((flips & 1) ? fc : fb);
-            u32 *e = reinterpret_cast<u32 *>(&A.ed[path[i]]);
+            u32 *e = reinterpret_cast<u32 *>(ed + path[i]);
             e[1] = f2u(u2f(e[1]) + val);
             e[2] += 1u;
         }
@@ -492,7 +519,7 @@ __device__ inline void backup_game_h(const EngineParams &P, int g, azh_game_stat
     s.leaf_kind = AZH_LEAF_NONE;
 }
 
-__device__ inline void mark_game_h(const EngineParams &P, int g, azh_game_state &s, int forced)
+__device__ inline void mark_game_h(const EngineParams &P, int g, HState &s, int forced)
 {
     if (s.phase == 1 && s.leaf_kind != AZH_LEAF_DESCENT && (s.root_visits >= P.visits || forced != 0)) {
         s.phase = 2;
@@ -501,26 +528,35 @@ __device__ inline void mark_game_h(const EngineParams &P, int g, azh_game_state 
     }
 }
 
+// per game 1 KiB of LDS: the move list of the node being expanded (select) / the root's gamma draws (backup)
+union HScratch {
+    u16 moves[MAX_MOVES];
+    float f[MAX_MOVES];
+};
+
 // the step-wise API's kernels: two games per 64-thread workgroup
 __global__ __launch_bounds__(WAVE) void k_select_h(EngineParams P)
 {
-    __shared__ u16 s_moves[2][MAX_MOVES];
+    __shared__ HScratch scr[2];
     const int g = 2 * (int)blockIdx.x + hw::half();
-    if (g < P.G) {
-        azh_game_state s = P.gs[g];
-        select_game_h(P, g, s, s_moves[hw::half()]);
-    }
+    if (g < P.G)
+        select_game_h(P, g, load_hstate(P.gs + g), scr[hw::half()].moves);
 }
 
 __global__ __launch_bounds__(WAVE) void k_backup_h(EngineParams P)
 {
+    __shared__ HScratch scr[2];
     const int g = 2 * (int)blockIdx.x + hw::half();
     if (g < P.G) {
-        azh_game_state s = P.gs[g];
+        HState s = load_hstate(P.gs + g);
         const int kind = s.leaf_kind;
-        backup_game_h(P, g, s);
-        if (kind != AZH_LEAF_NONE && kind != AZH_LEAF_DESCENT && hw::lane() == 0)
-            P.gs[g] = s;
+        backup_game_h(P, g, s, scr[hw::half()].f);
+        if (kind != AZH_LEAF_NONE && kind != AZH_LEAF_DESCENT && hw::lane() == 0) {
+            azh_game_state *gs = P.gs + g;
+            gs->phase = s.phase;
+            gs->root_visits = s.root_visits;
+            gs->leaf_kind = s.leaf_kind;
+        }
     }
 }
 
@@ -528,21 +564,31 @@ __global__ __launch_bounds__(WAVE) void k_mark_h(EngineParams P)
 {
     const int g = 2 * (int)blockIdx.x + hw::half();
     if (g < P.G) {
-        azh_game_state s = P.gs[g];
+        HState s = load_hstate(P.gs + g);
         const int phase = s.phase;
         mark_game_h(P, g, s, P.force[g]);
         if (s.phase != phase && hw::lane() == 0)
-            P.gs[g] = s;
+            P.gs[g].phase = s.phase;
     }
 }
 
 // k_tree with two games per wave: TREE_WAVES waves = 2 * TREE_WAVES games per workgroup; the leaf-list compaction by
 // the last workgroup is k_tree's (compact_leaves), with one net.
+// AZH_TREE_H_OCC: waves per SIMD the compiler must leave room for (register budget 512 / n per lane, the rest spills to
+// scratch); 0 = no bound.  16384 games are 8192 waves: 8 per SIMD keep them all resident, 7 keep 14336 games.
+#ifndef AZH_TREE_H_OCC
+#define AZH_TREE_H_OCC 0
+#endif
+#if AZH_TREE_H_OCC
+#define AZH_TREE_H_BOUNDS(threads) __launch_bounds__(threads, AZH_TREE_H_OCC)
+#else
+#define AZH_TREE_H_BOUNDS(threads) __launch_bounds__(threads)
+#endif
 template <bool STAMP, int TREE_WAVES>
-__global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree_h(EngineParams P, int mode)
+__global__ AZH_TREE_H_BOUNDS(TREE_WAVES * WAVE) void k_tree_h(EngineParams P, int mode)
 {
     constexpr int GAMES = 2 * TREE_WAVES;
-    __shared__ u16 s_moves[GAMES][MAX_MOVES];
+    __shared__ HScratch scr[GAMES];
     __shared__ int s_cnt[2 * TREE_WAVES];
     __shared__ int s_need[GAMES];
     __shared__ int s_last;
@@ -553,11 +599,11 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree_h(EngineParams P, in
     int need = 0;
     if constexpr (STAMP) st[0] = tree_stamp();
     if (g < P.G) {
-        azh_game_state s = P.gs[g];
+        HState s = load_hstate(P.gs + g);
         const int forced = P.force[g];
         if constexpr (STAMP) st[1] = tree_stamp();
         if (mode & 1) {
-            backup_game_h(P, g, s);
+            backup_game_h(P, g, s, scr[slot].f);
             if constexpr (STAMP) st[2] = tree_stamp();
             mark_game_h(P, g, s, forced);
         }
@@ -565,10 +611,14 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree_h(EngineParams P, in
             st[3] = tree_stamp();
             if (!(mode & 1)) st[2] = st[3];
         }
-        if (mode & 2)
-            need = select_game_h<STAMP>(P, g, s, s_moves[slot], st);
-        else if (hw::lane() == 0)
-            P.gs[g] = s;
+        if (mode & 2) {
+            need = select_game_h<STAMP>(P, g, s, scr[slot].moves, st);
+        } else if (hw::lane() == 0) {
+            azh_game_state *gs = P.gs + g;
+            gs->phase = s.phase;
+            gs->root_visits = s.root_visits;
+            gs->leaf_kind = s.leaf_kind;
+        }
     }
     if (!(mode & 2))
         return;
