@@ -19,9 +19,37 @@ import json
 from . import link, model, selfplay
 
 
+def random_openings(pairs, depth, seed):
+    """`pairs` openings of `depth` uniformly random plies from the start position — uai_ringmaster.get_opening
+    (uai_ringmaster.py:185-196: OPENING_DEPTH random.choice(board.legal_moves()) moves; the constant is 0 in the reference's
+    file and is edited there) — played by the HIP playout kernel.  -> (positions (pairs, 2) u64 packed x | turn << 63, o;
+    moves: per pairing the list of UAI strings).  Games that end inside the opening are not used."""
+    import numpy as np
+    x, o, bl, turn = selfplay.parse_fen(selfplay.START_FEN_PLAIN)
+    boards, moves = [], []
+    batch = 0
+    while len(boards) < pairs:
+        plies, results, trace, mv = link.random_play(2 * pairs + 16, (int(seed) << 8) + batch, x, o, bl, turn, max(depth + 1, 2))
+        batch += 1
+        for g in range(len(plies)):
+            if len(boards) < pairs and plies[g] > depth:        # still running after `depth` plies
+                bx, bo = int(trace[g, depth, 0]) & ((1 << 63) - 1), int(trace[g, depth, 1])
+                boards.append([bx | ((depth & 1) << 63), bo])
+                moves.append([uai_move(int(m)) for m in mv[g, :depth]])
+    return np.array(boards, dtype=np.uint64), moves
+
+
+def uai_move(mv):
+    """u16 (from | to << 8, square = file + 7 * rank) -> UAI text (uai_interface.py:11-22)"""
+    def sq(s):
+        return "abcdefg"[s % 7] + str(s // 7 + 1)
+    frm, to = mv & 0xFF, mv >> 8
+    return sq(to) if frm == to else sq(frm) + sq(to)
+
+
 class Match:
     def __init__(self, weights_a, weights_b, visits, games=1024, dtype="f16", seed=selfplay.DEFAULT_SEED,
-                 max_plies=400):
+                 max_plies=400, opening_depth=0):
         if games % 2:
             raise ValueError("the number of concurrent games must be even (each pairing is played both ways)")
         self.net_a = link.Net(*weights_a, model.BN_EPSILON)
@@ -31,6 +59,15 @@ class Match:
                                    dirichlet_weight=0.0, flags=link.FLAG_ARENA)
         self.engine = link.Engine(cfg)
         self.games = games
+        self.opening_depth = opening_depth
+        self.openings = None
+        if opening_depth > 0:
+            # every pairing gets its own random opening, played both ways (uai_ringmaster.py:242-246): slots 2k and 2k + 1
+            # start from the same position.  Only the FIRST game of a slot starts from it (uid < games): a match from
+            # openings is a cohort of at most `games` games.
+            import numpy as np
+            boards, self.openings = random_openings(games // 2, opening_depth, seed)
+            self.engine.set_positions(np.repeat(boards, 2, axis=0), np.full(games, opening_depth, dtype=np.int32))
 
     def run(self, iterations):
         self.engine.run_arena(self.net_a, self.net_b, iterations, self.dtype)
@@ -42,8 +79,12 @@ class Match:
         for line in self.engine.drain_json():
             e = json.loads(line)
             white = "a" if e["slot"] % 2 == 0 else "b"
+            opening = []
+            if self.openings is not None and e["uid"] < self.games:
+                opening = self.openings[e["uid"] // 2]
+                e["moves"] = opening + e["moves"]          # (boards[] starts after the opening; only its last entry is used)
             out.append({"moves": e["moves"], "result": e["result"], "white": white, "uid": e["uid"],
-                        "final_score": replay_final_score(e), "boards": e["boards"]})
+                        "final_score": replay_final_score(e), "boards": e["boards"], "opening": opening})
         return out
 
     def close(self):
@@ -89,7 +130,7 @@ def write_game_to_pgn(path, game, white_name, black_name, round_index, tc):
         print('[Round "%i"]' % (round_index,), file=f)
         print('[White "%s"]' % (white_name,), file=f)
         print('[Black "%s"]' % (black_name,), file=f)
-        print('[Opening "%s"]' % ("",), file=f)
+        print('[Opening "%s"]' % (", ".join(game.get("opening", [])),), file=f)
         print('[GameStartTime "%s"]' % (now.isoformat(),), file=f)
         print('[GameEndTime "%s"]' % (now.isoformat(),), file=f)
         print('[Plycount "%i"]' % (len(game["moves"]),), file=f)

@@ -2204,9 +2204,11 @@ static void format_staged(azh_engine *e)
         const uint32_t *rec = host.data() + o.second;
         const bool dropped = rec[7] == 1;
         std::string line = dropped ? std::string() : azh_format_game_json(rec, rec[5], ids);
-        if (rec[7] == 2)
+        if (rec[7] == 2 && !ids)
             line.clear();  // a game that began at a loaded position: record drained and formatted like any other
-                           // (the measured path does the same work per finished ply), but it is not a whole game
+                           // (the measured path does the same work per finished ply), but it is not a whole game.
+                           // (The arena hands such games out: a match from given openings — uai_ringmaster.py:185-196 —
+                           // loads the position after the opening; the caller knows the opening moves.)
         if (e->emit_by_uid && !e->order_broken)
             e->held[o.first] = std::move(line);
         else if (!line.empty())

@@ -94,6 +94,57 @@ def test_batched_two_net_match_bookkeeping():
             assert len(g["moves"]) == 300  # cut -> annulled
 
 
+def test_match_from_random_openings(tmp_path):
+    """uai_ringmaster.get_opening (uai_ringmaster.py:185-196, OPENING_DEPTH random plies, the same opening for both games of a
+    pairing) as arena.Match(opening_depth=N) / `uai_ringmaster.py --opening-depth N`: the slots are loaded with the positions
+    after the openings; the games come back with the opening in front of their moves, replay from the start position, and
+    the two games of a pairing share their opening while different pairings do not."""
+    nets = [model.random_init(2, 128, seed=s) for s in (21, 22)]
+    m = arena.Match(nets[0], nets[1], visits=16, games=64, dtype="f16", seed=9, max_plies=400, opening_depth=4)
+    done = {}
+    for _ in range(600):
+        m.run(50)
+        for g in m.drain():
+            if g["uid"] < 64:
+                done[g["uid"]] = g
+        if len(done) == 64:
+            break
+    m.close()
+    assert len(done) == 64
+    for uid, g in done.items():
+        assert len(g["opening"]) == 4 and g["moves"][:4] == g["opening"] and g["opening"] == done[uid ^ 1]["opening"]
+        assert g["white"] == ("a" if uid % 2 == 0 else "b")
+        p = orc.pos_from_fen(orc.START_FEN_PLAIN)                  # the whole game is legal from the start position
+        for mv in g["moves"]:
+            assert orc.result(p) == 0 and mv in [orc.move_string(x) for x in orc.movegen(p)], (uid, mv)
+            c = orc.move_from_string(mv)
+            orc.lib().orc_makemove(p, c & 0xFF, c >> 8)
+        assert orc.result(p) == g["result"] != 0
+        x, o = g["final_score"]
+        cells = [int(v) for v in orc.board_cells(p)]
+        assert (cells.count(1), cells.count(2)) == (x, o)
+    assert len({tuple(g["opening"]) for g in done.values()}) > 20
+    # the command line, with the reference's `with opening: [...]` line and [Opening "..."] tag filled in
+    pa, pb = str(tmp_path / "a.npy"), str(tmp_path / "b.npy")
+    model.save_model(pa, *nets[0])
+    model.save_model(pb, *nets[1])
+    pgn = str(tmp_path / "out.pgn")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "uai_ringmaster.py"),
+                          "--engine", "python uai_interface.py --network-path %s --visits 8" % pa,
+                          "--engine", "python uai_interface.py --network-path %s --visits 8" % pb,
+                          "--pgn-out", pgn, "--game-count", "20", "--opening-depth", "3"], cwd=ROOT, capture_output=True, timeout=400)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    openings = re.findall(r"with opening: \[([a-g1-7, ]+)\]", res.stdout.decode())
+    assert len(openings) == 20 and all(len(o.split(", ")) == 3 for o in openings)
+    text = open(pgn).read()
+    assert len(re.findall(r'\[Opening "[a-g1-7, ]+"\]', text)) == 20
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "uai_ringmaster.py"),
+                          "--engine", "python uai_interface.py --network-path %s --visits 8" % pa,
+                          "--engine", "python uai_interface.py --network-path %s --visits 8" % pb,
+                          "--game-count", "5000", "--opening-depth", "3"], cwd=ROOT, capture_output=True, timeout=400)
+    assert res.returncode != 0 and b"--opening-depth needs the whole match in flight" in res.stderr
+
+
 def test_uai_ringmaster_cli(tmp_path):
     conv, bn = model.random_init(1, 128, seed=2)
     conv2, bn2 = model.random_init(1, 128, seed=3)

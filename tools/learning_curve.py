@@ -117,6 +117,8 @@ def arena(args, k, out, other=1):
            "--engine", eng % (model_path(args.prefix, k), args.arena_visits),
            "--engine", eng % (model_path(args.prefix, other), args.arena_visits),
            "--game-count", str(args.arena_games), "--seed", str(args.seed + 31 * k + other)]
+    if args.arena_opening_depth > 0:
+        cmd += ["--opening-depth", str(args.arena_opening_depth)]
     t0 = time.time()
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
     if res.returncode != 0:
@@ -124,7 +126,17 @@ def arena(args, k, out, other=1):
         raise SystemExit(2)
     wins = re.findall(r"^Wins: ([0-9.]+) - ([0-9.]+) \(annulled: (\d+)\)", res.stdout, re.M)
     a, b, ann = float(wins[-1][0]), float(wins[-1][1]), int(wins[-1][2])
-    return {"new": a, "first": b, "annulled": ann, "score": a / (a + b), "seconds": round(time.time() - t0, 1)}
+    # an annulled game (cut at 400 plies: the rules have no repetition or move-count draw) counts half a point each in the
+    # ringmaster's tally; over the DECISIVE games alone the score says who wins when somebody does
+    decisive = a + b - ann
+    return {"new": a, "first": b, "annulled": ann, "score": a / (a + b), "decisive_games": int(decisive),
+            "decisive_score": (a - 0.5 * ann) / decisive if decisive > 0 else float("nan"),
+            "seconds": round(time.time() - t0, 1)}
+
+
+def match_line(label, r):
+    return "%s: %.1f - %.1f (annulled %d) = %.1f %%; decisive games %d: %.1f %%   [%.0f s]" % (
+        label, r["new"], r["first"], r["annulled"], 100.0 * r["score"], r["decisive_games"], 100.0 * r["decisive_score"], r["seconds"])
 
 
 def value_check(model_file, games_file, samples=4096, seed=7):
@@ -168,6 +180,10 @@ def main():
     ap.add_argument("--training-window-exclude", type=int, default=3)       # looper.py:112
     ap.add_argument("--arena-games", type=int, default=1000)
     ap.add_argument("--arena-visits", type=int, default=100)
+    ap.add_argument("--arena-opening-depth", type=int, default=0,
+                    help="matches start from random openings of this many plies (uai_ringmaster.py --opening-depth): two "
+                         "near-deterministic nets otherwise shuffle to the 400-ply cut game after game")
+    ap.add_argument("--anchor", type=int, default=0, help="> 1: also play every later generation against model-<anchor>")
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--seed", type=int, default=1)
@@ -223,16 +239,21 @@ def main():
     log(out, "")
     log(out, "arena: model-00k vs model-001, %d games (every pairing both ways), %d visits/move" % (
         args.arena_games, args.arena_visits))
+    if args.arena_opening_depth > 0:
+        log(out, "(every pairing from its own opening of %d uniformly random plies, played both ways: uai_ringmaster.py:185-196)"
+            % args.arena_opening_depth)
     for k in range(2, args.iterations + 2):
-        r = arena(args, k, out)
-        log(out, "model-%03i vs model-001: %.1f - %.1f (annulled %d) = %.1f %%   [%.0f s]" % (
-            k, r["new"], r["first"], r["annulled"], 100.0 * r["score"], r["seconds"]))
+        log(out, match_line("model-%03i vs model-001" % k, arena(args, k, out)))
     log(out, "")
     log(out, "arena: every generation against its parent (the net it was trained from), same match size")
     for k in range(3, args.iterations + 2):
-        r = arena(args, k, out, other=k - 1)
-        log(out, "model-%03i vs model-%03i: %.1f - %.1f (annulled %d) = %.1f %%   [%.0f s]" % (
-            k, k - 1, r["new"], r["first"], r["annulled"], 100.0 * r["score"], r["seconds"]))
+        log(out, match_line("model-%03i vs model-%03i" % (k, k - 1), arena(args, k, out, other=k - 1)))
+    if args.anchor > 1 and args.anchor <= args.iterations + 1:
+        log(out, "")
+        log(out, "arena: the later generations against the anchor model-%03i (a net that already plays: the first net stops "
+                 "telling generations apart once they all beat it every time)" % args.anchor)
+        for k in range(args.anchor + 1, args.iterations + 2):
+            log(out, match_line("model-%03i vs model-%03i" % (k, args.anchor), arena(args, k, out, other=args.anchor)))
     log(out, "")
     log(out, "value head and policy of model-00k on the games model-00k itself went on to play (positions it was NOT trained on), "
              "through training.make_minibatch's encoders and the HIP tower (f32):")

@@ -37,7 +37,11 @@ if __name__ == "__main__":
         flag("--engine", "engine command line (twice): python uai_interface.py --network-path X.npy --visits N",
              metavar="CMD", action="append"),
         switch("--show-games", "reference flag, not provided by the batched arena"),
-        flag("--opening", "reference flag; only the empty opening is provided", metavar="MOVES"),
+        flag("--opening", "reference flag; only the empty opening is provided (random openings: --opening-depth)", metavar="MOVES"),
+        flag("--opening-depth", "every pairing starts from its own opening of N uniformly random plies, played both ways — the "
+                                "reference's get_opening with its module constant OPENING_DEPTH (uai_ringmaster.py:7,185-196) as a "
+                                "flag.  Two near-deterministic engines otherwise replay the same few games; needs --game-count <= "
+                                "the games in flight", type=int, default=0, metavar="N"),
         flag("--max-plies", "games longer than this are cut and annulled", type=int, metavar="N"),
         flag("--pgn-out", "PGN file the games are appended to", metavar="PGN"),
         switch("--gauntlet", "first engine against all others (with two engines: the same match)"),
@@ -66,10 +70,14 @@ if __name__ == "__main__":
     selfplay.select_device(0)
     concurrent = args.concurrent or min(2048, args.game_count + args.game_count % 2)
     concurrent += concurrent % 2
+    if args.opening_depth > 0 and args.game_count > concurrent:
+        raise SystemExit("uai_ringmaster.py: --opening-depth needs the whole match in flight (--game-count %d > %d games; "
+                         "raise --concurrent)" % (args.game_count, concurrent))
     match = arena.Match(model.load_model(path_a), model.load_model(path_b), visits_a, games=concurrent, dtype=args.dtype,
                         seed=args.seed,
                         # the reference stops a game once ply_number > --max-plies (uai_ringmaster.py:139-140): N + 1 moves
-                        max_plies=args.max_plies + 1 if args.max_plies is not None else 400)
+                        max_plies=args.max_plies + 1 if args.max_plies is not None else 400,
+                        opening_depth=args.opening_depth)
     names = {"a": " ".join(engines[0]), "b": " ".join(engines[1])}
     wins = {"a": 0, "b": 0}
     annulled = 0
@@ -87,7 +95,7 @@ if __name__ == "__main__":
                 continue  # a replacement game started in a slot whose cohort games are done
             white = game["white"]
             black = "b" if white == "a" else "a"
-            print('Game: "%s" vs "%s" with opening: []' % (names[white], names[black]))
+            print('Game: "%s" vs "%s" with opening: [%s]' % (names[white], names[black], ", ".join(game["opening"])))
             if game["result"] in (1, 2):
                 wins[white if game["result"] == 1 else black] += 1
             else:
