@@ -322,11 +322,22 @@ __device__ inline u32 ballot(bool p)
     return half() ? (u32)(m >> 32) : (u32)m;
 }
 
-// value of lane `src` (0..31, the same in all lanes of the game) of my game: one LDS-crossbar hop (ds_bpermute_b32; a
-// lane only ever reads from its own game, whose lanes are active whenever it is)
+// value of lane `src` (0..31, the same in all lanes of the game) of my game: each game's index and value through scalar
+// registers (v_readlane ignores EXEC, so this also works while the other game of the wave sits out a branch — what it reads
+// for that game is then unused).  (The first version went through the LDS crossbar — ds_bpermute_b32 — and paid its latency
+// five times per tree level, in series: profiles/round4_halfwave_first_version_stamps.txt.)
 __device__ inline int read_lane(int v, int src)
 {
-    return __builtin_amdgcn_ds_bpermute((src + (int)(threadIdx.x & 32)) << 2, v);
+    const int s0 = __builtin_amdgcn_readlane(src, 0), s1 = __builtin_amdgcn_readlane(src, 32);
+    const int a = __builtin_amdgcn_readlane(v, s0), b = __builtin_amdgcn_readlane(v, s1 + 32);
+    return (threadIdx.x & 32) ? b : a;
+}
+
+// value of lane 31 of my game
+__device__ inline int last_lane(int v)
+{
+    const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
+    return (threadIdx.x & 32) ? b : a;
 }
 
 // rows 0 <-> 1 (and 2 <-> 3) exchanged lane for lane: gfx950's v_permlane16_swap
@@ -401,7 +412,7 @@ __device__ inline int incl_scan(int v)
     return v;
 }
 
-__device__ inline int bcast_last(int v) { return read_lane(v, 31); }
+__device__ inline int bcast_last(int v) { return last_lane(v); }
 
 // what a game's lanes hand each other through LDS or memory (see wave_sync above; the two games of a wave never share data)
 __device__ inline void sync() { wave_sync(); }

@@ -12,6 +12,12 @@
 //     sum (softmax denominator, Dirichlet total) the lane keeps two partial sums — elements with (j / 32) even and odd,
 //     i.e. virtual lanes l and l + 32 of the 64-lane order — and hw::sum_f32 combines them exactly as the 64-lane
 //     butterfly does.  The oracle does not change.
+//   * the two games of a wave run in lockstep, and a branch only one of them takes is time the other one waits: whatever
+//     waits for memory is therefore written as ONE instruction stream for both — every level of a descent loads up to four
+//     records per lane (128 children) under lane predicates instead of choosing between a short and a general path, and the
+//     backup requests the leaf's moves, the logits and the path's edges for both games together — so that a tree level
+//     costs one memory round trip per WAVE.  (The first version kept select_game's branches: a level cost 1.4 us against
+//     0.97 with 4096 games and the launch was slower than one wave per game, profiles/round4_halfwave_first_version_*.txt.)
 // Not provided on 32 lanes (the engine keeps one wave per game for them): the arena's flags (AZH_FLAG_PY_POSTERIOR's
 // 833-way softmax, two nets) — arena batches are a thousand games, far from the 8192 where this matters.
 
@@ -80,6 +86,11 @@ __device__ inline int select_game_h(const EngineParams &P, int g, const HState &
     int kind = AZH_LEAF_NONE, leaf_node = 0, depth = 0;
     // bit 0: an MCTS step begins, 1: evaluation found in the tree, 2: edge arena overflow
     u32 flags = 0, st_levels = 0, st_children = 0, st_newmoves = 0;
+    u32 node = 0, sel_eidx = 0;
+    bool expand = false;
+    int path_base = 0;
+    u32 path_buf0 = 0, path_buf1 = 0;
+    auto path_of = [&]() { return P.path + (size_t)g * P.path_cap; };
 
     if (s.phase >= 2) {
         kind = AZH_LEAF_NONE;  // the move is due (its re-root runs after this select) or the slot is idle
@@ -94,8 +105,9 @@ __device__ inline int select_game_h(const EngineParams &P, int g, const HState &
     } else {
         const bool resume = s.leaf_kind == AZH_LEAF_DESCENT;
         flags = resume ? 0u : 1u;
-        u32 node = resume ? (u32)s.leaf_node : 0u;
+        node = resume ? (u32)s.leaf_node : 0u;
         depth = resume ? s.path_len : 0;
+        path_base = depth;
         u32 kid;
         {
             const uint4 rinfo = P.node_info[(size_t)slot * P.node_cap + node];
@@ -106,9 +118,6 @@ __device__ inline int select_game_h(const EngineParams &P, int g, const HState &
         u32 n_node = (u32)s.root_visits;
         // the path entries of this launch: lane k keeps entries k and k + 32, stored together afterwards (every 64 levels
         // when there is no budget)
-        u32 path_buf0 = 0, path_buf1 = 0;
-        int path_base = depth;
-        auto path_of = [&]() { return P.path + (size_t)g * P.path_cap; };
         auto push_path = [&](u32 eidx) {
             const int k = depth - path_base;
             if (l == (k & 31)) {
@@ -123,23 +132,23 @@ __device__ inline int select_game_h(const EngineParams &P, int g, const HState &
                 path_base = depth;
             }
         };
-        uint4 ea0 = fresh_edge(0u), ea1 = fresh_edge(0u);
-        bool cur_loaded = false;
-        auto load_children = [&](u32 k, uint4 &r0, uint4 &r1) {
-            const int cnt = kid_count(k);
-            const uint4 *f = ed + kid_first(k) + (u32)l;
-            r0 = fresh_edge(0u);
-            r1 = fresh_edge(0u);
-            if (l < cnt)
-                r0 = f[0];
-            if (l + HL < cnt)
-                r1 = f[HL];
+        // the records of children base + l + 32 k (k = 0..3) of the node whose range is `k`: up to 128 children in one go
+        uint4 ev[4];
+        auto load_level = [&](u32 range, int base) {
+            const int cnt = kid_count(range);
+            const uint4 *f = ed + kid_first(range) + (u32)(base + l);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ev[k] = fresh_edge(0u);
+                if (base + l + HL * k < cnt)
+                    ev[k] = f[HL * k];
+            }
         };
-        u32 sel_eidx = 0;
-        bool expand = false;
+        if (!kid_finished(kid))
+            load_level(kid, 0);
         for (;;) {
             if (P.select_budget != 0 && levels_done == P.select_budget) {
-                kind = AZH_LEAF_DESCENT;
+                kind = AZH_LEAF_DESCENT;  // park: no leaf for the evaluator from this game this iteration
                 leaf_node = (int)node;
                 break;
             }
@@ -147,228 +156,183 @@ __device__ inline int select_game_h(const EngineParams &P, int g, const HState &
             const int M = kid_count(kid);
             const u32 first = kid_first(kid);
             if (kid_finished(kid) || M == 0) {
-                kind = AZH_LEAF_TERMINAL;
+                kind = AZH_LEAF_TERMINAL;  // select_action -> NO_MOVE (:336-340)
                 leaf_node = (int)node;
                 break;
             }
             st_levels += 1;
             st_children += (u32)M;
-            u32 zsel, wsel, eidx;
-            if (M <= 2 * HL) {
-                // fast path: up to 64 children, two records per lane; the same arithmetic as select_game's
-                if (!cur_loaded)
-                    load_children(kid, ea0, ea1);
-                cur_loaded = false;
-                const uint4 e0 = ea0, e1 = ea1;
-                uint4 en0 = fresh_edge(0u), en1 = fresh_edge(0u);
-                const bool live0 = l < M, live1 = l + HL < M;
-                // the remembered child, requested before anything is scored
-                const u32 unv0 = hw::ballot(live0 && edge_child(e0) == ENONE);
-                const u32 unv1 = hw::ballot(live1 && edge_child(e1) == ENONE);
-                int u0 = -1, pv = -1, pred = -1;
-                if (unv0 | unv1) {
-                    u0 = unv0 ? __ffs((int)unv0) - 1 : HL + __ffs((int)unv1) - 1;
-                    const u32 hint = (u32)hw::read_lane((int)(u0 < HL ? e0.w : e1.w), u0 & 31);
-                    if ((hint >> 31) && (int)(hint & 0xFFu) < M) {
-                        pv = (int)(hint & 0xFFu);
-                        const u32 pz = (u32)hw::read_lane((int)(pv < HL ? e0.z : e1.z), pv & 31);
-                        const u32 pk = (u32)hw::read_lane((int)(pv < HL ? e0.w : e1.w), pv & 31);
-                        if ((pz >> 16) != ENONE && !kid_finished(pk) && kid_count(pk) > 0 && kid_count(pk) <= 2 * HL) {
-                            load_children(pk, en0, en1);
-                            pred = pv;
-                        }
-                    }
-                }
-                const u32 n0 = edge_visits(e0), n1 = edge_visits(e1);
-                const u32 ntot1 = have_n ? n_node : hw::sum_u32(n0 + n1);
-                const float sq1 = sqrtf((float)(1u + ntot1));
-                u32 bits0, bits1;
-                bool valid0, valid1;
-                {
-                    const float prior = u2f(e0.x);
-                    const float W = u2f(e0.y);
-                    const float q = n0 ? W / (float)n0 : 0.0f;
-                    const float u = (sq1 / (1.0f + (float)n0)) * (P.c_puct * prior);
-                    const float score = u + q;
-                    valid0 = live0 && score >= 0.0f;
-                    bits0 = valid0 ? f2u(score + 0.0f) : 0u;
-                }
-                {
-                    const float prior = u2f(e1.x);
-                    const float W = u2f(e1.y);
-                    const float q = n1 ? W / (float)n1 : 0.0f;
-                    const float u = (sq1 / (1.0f + (float)n1)) * (P.c_puct * prior);
-                    const float score = u + q;
-                    valid1 = live1 && score >= 0.0f;
-                    bits1 = valid1 ? f2u(score + 0.0f) : 0u;
-                }
-                const u32 top = hw::max_u32(bits0 > bits1 ? bits0 : bits1);
-                const u32 cand0 = hw::ballot(valid0 && bits0 == top);
-                const u32 cand1 = hw::ballot(valid1 && bits1 == top);
-                int bj = 0;
-                if (P.flags & AZH_FLAG_TIE_FIRST) {
-                    if (cand0)
-                        bj = __ffs((int)cand0) - 1;
-                    else if (cand1)
-                        bj = HL + __ffs((int)cand1) - 1;
+            // N of the node (see select_game): known from the edge that led here, except on a resumed descent
+            u32 ntot = n_node;
+            if (!have_n) {
+                u32 nsum = 0;
+                if (M <= 4 * HL) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        nsum += edge_visits(ev[k]);   // (records that were not loaded hold 0 visits)
                 } else {
-                    if (cand1)
-                        bj = HL + 31 - __clz((int)cand1);
-                    else if (cand0)
-                        bj = 31 - __clz((int)cand0);
-                }
-                eidx = first + (u32)bj;
-                zsel = (u32)hw::read_lane((int)(bj < HL ? e0.z : e1.z), bj & 31);
-                wsel = (u32)hw::read_lane((int)(bj < HL ? e0.w : e1.w), bj & 31);
-                if ((zsel >> 16) != ENONE) {
-                    if (u0 >= 0 && bj != pv && l == 0)
-                        reinterpret_cast<u32 *>(ed + first + (u32)u0)[3] = 0x80000000u | (u32)bj;
-                    if (pred == bj) {
-                        ea0 = en0;
-                        ea1 = en1;
-                        cur_loaded = true;
-                    }
-                }
-            } else {
-                // general path: 65..256 children in chunks of 128 (four records per lane), a running 64-bit (score, index)
-                // key as in select_game; a second chunk (more than 128 moves: rare) costs a second round trip
-                u32 ntot = n_node;
-                if (!have_n) {   // a resumed descent does not know the node's N: sum the children's visits first
-                    u32 nsum = 0;
                     for (int j = l; j < M; j += HL)
                         nsum += reinterpret_cast<const u32 *>(ed + first + (u32)j)[2] & 0xFFFFu;
-                    ntot = hw::sum_u32(nsum);
                 }
-                const float sq = sqrtf((float)(1u + ntot));
-                const u32 tie_flip = (P.flags & AZH_FLAG_TIE_FIRST) ? 0xFFFFFFFFu : 0u;
-                u64 key = 0;
-                u32 mine = ENONE << 16, mkid = 0u;
-                for (int base = 0; base < M; base += 4 * HL) {
-                    uint4 ev[4];
+                ntot = hw::sum_u32(nsum);
+            }
+            const float sq = sqrtf((float)(1u + ntot));
+            // arg-max of the score bits (scores are >= 0, their bit patterns order like the floats), ties to the LAST maximal
+            // edge (:354) or the first (the arena's python max(), engine.py:291); NaN scores and empty lanes never win
+            u32 best_bits = 0, best_z = 0, best_w = 0;
+            int best_j = -1;
+            for (int base = 0;;) {
+                u32 bits[4];
+                bool valid[4];
+                u32 top = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int j = base + l + HL * k;
-                        ev[k] = fresh_edge(0u);
-                        if (j < M)
-                            ev[k] = ed[first + (u32)j];
-                    }
-                    if (base == 0) {
-                        mine = ev[0].z;   // key 0 (no valid score anywhere) selects edge 0 = lane 0's first record
-                        mkid = ev[0].w;
-                    }
+                for (int k = 0; k < 4; k++) {
+                    const float prior = u2f(ev[k].x);
+                    const u32 n = edge_visits(ev[k]);
+                    const float W = u2f(ev[k].y);
+                    const float q = n ? W / (float)n : 0.0f;
+                    const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
+                    const float score = u + q;
+                    valid[k] = base + l + HL * k < M && score >= 0.0f;
+                    bits[k] = valid[k] ? f2u(score + 0.0f) : 0u;
+                    top = bits[k] > top ? bits[k] : top;
+                }
+                top = hw::max_u32(top);
+                // who holds `top` in this chunk: one ballot per row of records; the rows are visited so that the LAST hit is
+                // the tie rule's choice (highest index for the last-max rule, lowest for the first-max rule)
+                const bool tie_first = (P.flags & AZH_FLAG_TIE_FIRST) != 0;
+                u32 cand[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int j = base + l + HL * k;
-                        if (j < M) {
-                            const float prior = u2f(ev[k].x);
-                            const u32 n = edge_visits(ev[k]);
-                            const float W = u2f(ev[k].y);
-                            const float q = n ? W / (float)n : 0.0f;
-                            const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
-                            const float score = u + q;
-                            const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)((u32)j ^ tie_flip) : 0ull;
-                            if (kj > key) {
-                                key = kj;
-                                mine = ev[k].z;
-                                mkid = ev[k].w;
-                            }
+                for (int k = 0; k < 4; k++)
+                    cand[k] = hw::ballot(valid[k] && bits[k] == top);
+                int ck = -1, cl = 0;
+                if (!tie_first) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (cand[k]) {
+                            ck = k;
+                            cl = 31 - __clz((int)cand[k]);
                         }
-                    }
-                }
-                key = hw::max_u64(key);
-                const int bj = key ? (int)((u32)key ^ tie_flip) : 0;
-                eidx = first + (u32)bj;
-                zsel = (u32)hw::read_lane((int)mine, bj & 31);
-                wsel = (u32)hw::read_lane((int)mkid, bj & 31);
-                ea0 = fresh_edge(0u);   // (nothing is requested early on this path: the buffers are dead here)
-                ea1 = fresh_edge(0u);
-                cur_loaded = false;
-            }
-            push_path(eidx);
-            if ((zsel >> 16) != ENONE) {
-                node = zsel >> 16;
-                kid = wsel;
-                n_node = (zsel & 0xFFFFu) - 1u;
-                have_n = true;
-                continue;
-            }
-            sel_eidx = eidx;
-            expand = true;
-            break;
-        }
-        if (expand) {
-            // expand (:429-439)
-            if constexpr (STAMP) st[4] = tree_stamp();
-            const u32 eidx = sel_eidx;
-            const size_t nbase = (size_t)slot * P.node_cap, ebase = (size_t)slot * P.edge_cap;
-            const u32 mv = P.edge_move[ebase + eidx];
-            const ulonglong2 pw = P.node_board[nbase + node];
-            const int2 counts = *reinterpret_cast<const int2 *>(&gs->n_nodes);   // (n_nodes, n_edges): not kept over the descent
-            const Board cb = make_move(unpack_board(pw.x, pw.y), (int)(mv & 0xFF), (int)(mv >> 8));
-            int res2;
-            const int M2 = hw::movegen(cb, P.blockers, s_moves, &res2);
-            hw::sync();
-            if (counts.x >= P.node_cap || (res2 == 0 && (counts.y + M2 > P.edge_cap || M2 > 255))) {
-                flags |= 4u;
-                kind = AZH_LEAF_NONE;
-                leaf_node = 0;
-                depth = 0;
-                path_base = 0;
-                if (l == 0)
-                    P.leaf_board[g] = make_ulonglong2(0ull, 0ull);
-            } else {
-                const u32 cid = (u32)counts.x;
-                const u32 nf = (u32)counts.y;
-                u32 known = NONE;
-                if ((P.flags & AZH_FLAG_EVAL_CACHE) && res2 == 0) {
-                    Arena A = arena_of(P, s.arena, g);
-                    known = tt_lookup_h(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, A, pack_word0(cb), cb.o);
-                }
-                int added = 0;
-                if (res2 != 0) {
-                    float tv = res2 == 1 ? 1.0f : -1.0f;
-                    if (cb.turn == 1)
-                        tv = -tv;
-                    if (l == 0)
-                        P.node_info[nbase + cid] = make_uint4(0u, (u32)res2 << 16, 0u, f2u(tv));
-                    kind = AZH_LEAF_TERMINAL;
-                } else if (known != NONE) {
-                    // same position, same moves in the same order: take the priors and the value, no evaluation
-                    const uint4 kinfo = P.node_info[nbase + known];
-                    for (int j = l; j < M2; j += HL) {
-                        ed[nf + j] = fresh_edge(ed[kinfo.x + j].x);
-                        P.edge_move[ebase + nf + j] = s_moves[j];
-                    }
-                    added = M2;
-                    if (l == 0)
-                        P.node_info[nbase + cid] = make_uint4(nf, (u32)M2, 0u, kinfo.w);
-                    kind = AZH_LEAF_TERMINAL;  // "value known": backed up from node_info.w like a finished position
-                    flags |= 2u;
-                    st_newmoves = (u32)M2;
                 } else {
-                    for (int j = l; j < M2; j += HL) {
-                        ed[nf + j] = fresh_edge(0u);
-                        P.edge_move[ebase + nf + j] = s_moves[j];
-                    }
-                    added = M2;
-                    if (l == 0)
-                        P.node_info[nbase + cid] = make_uint4(nf, (u32)M2, 0u, 0u);
-                    kind = AZH_LEAF_EVAL;
-                    st_newmoves = (u32)M2;
+#pragma unroll
+                    for (int k = 3; k >= 0; k--)
+                        if (cand[k]) {
+                            ck = k;
+                            cl = __ffs((int)cand[k]) - 1;
+                        }
                 }
-                if (l == 0) {
-                    P.node_board[nbase + cid] = make_ulonglong2(pack_word0(cb), cb.o);
-                    // the edge gets its child and the child's range
-                    reinterpret_cast<uint2 *>(ed + eidx)[1] =
-                        make_uint2(cid << 16, res2 != 0 ? pack_kid(0u, 0u, 1u) : pack_kid(nf, (u32)M2, 0u));
-                    *reinterpret_cast<int2 *>(&gs->n_nodes) = make_int2(counts.x + 1, counts.y + added);
-                    P.leaf_board[g] = cb.turn ? make_ulonglong2(cb.o, cb.x) : make_ulonglong2(cb.x, cb.o);
+                // across chunks (more than 128 moves): a later chunk wins ties under the last-max rule, loses them under the first
+                if (ck >= 0 && (best_j < 0 || top > best_bits || (top == best_bits && !tie_first))) {
+                    const u32 vz = ck == 0 ? ev[0].z : (ck == 1 ? ev[1].z : (ck == 2 ? ev[2].z : ev[3].z));
+                    const u32 vw = ck == 0 ? ev[0].w : (ck == 1 ? ev[1].w : (ck == 2 ? ev[2].w : ev[3].w));
+                    best_bits = top;
+                    best_j = base + HL * ck + cl;
+                    best_z = (u32)hw::read_lane((int)vz, cl);
+                    best_w = (u32)hw::read_lane((int)vw, cl);
                 }
-                leaf_node = (int)cid;
+                base += 4 * HL;
+                if (base >= M)
+                    break;
+                load_level(kid, base);   // (rare: a second round trip for the children beyond 128)
             }
-        } else if (l == 0) {
-            P.leaf_board[g] = make_ulonglong2(0ull, 0ull);
+            u32 zsel = best_z, wsel = best_w;
+            int bj = best_j;
+            if (bj < 0) {   // no valid score anywhere (NaN priors): edge 0, as select_game's key 0 does
+                bj = 0;
+                const uint4 e = ed[first];
+                zsel = e.z;
+                wsel = e.w;
+            }
+            const u32 eidx = first + (u32)bj;
+            push_path(eidx);
+            if ((zsel >> 16) == ENONE) {
+                sel_eidx = eidx;
+                expand = true;
+                break;
+            }
+            node = zsel >> 16;
+            kid = wsel;
+            n_node = (zsel & 0xFFFFu) - 1u;
+            have_n = true;
+            // the next level's records, requested at once (none for a finished position, none when the budget parks the descent)
+            if (!kid_finished(kid) && !(P.select_budget != 0 && levels_done == P.select_budget))
+                load_level(kid, 0);
         }
+    }
+    if (expand) {
+        // expand (:429-439)
+        if constexpr (STAMP) st[4] = tree_stamp();
+        const u32 eidx = sel_eidx;
+        const size_t nbase = (size_t)slot * P.node_cap, ebase = (size_t)slot * P.edge_cap;
+        const u32 mv = P.edge_move[ebase + eidx];
+        const ulonglong2 pw = P.node_board[nbase + node];
+        const int2 counts = *reinterpret_cast<const int2 *>(&gs->n_nodes);   // (n_nodes, n_edges): not kept over the descent
+        const Board cb = make_move(unpack_board(pw.x, pw.y), (int)(mv & 0xFF), (int)(mv >> 8));
+        int res2;
+        const int M2 = hw::movegen(cb, P.blockers, s_moves, &res2);
+        hw::sync();
+        if (counts.x >= P.node_cap || (res2 == 0 && (counts.y + M2 > P.edge_cap || M2 > 255))) {
+            flags |= 4u;
+            kind = AZH_LEAF_NONE;
+            leaf_node = 0;
+            depth = 0;
+            path_base = 0;
+            if (l == 0)
+                P.leaf_board[g] = make_ulonglong2(0ull, 0ull);
+        } else {
+            const u32 cid = (u32)counts.x;
+            const u32 nf = (u32)counts.y;
+            u32 known = NONE;
+            if ((P.flags & AZH_FLAG_EVAL_CACHE) && res2 == 0) {
+                Arena A = arena_of(P, s.arena, g);
+                known = tt_lookup_h(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, A, pack_word0(cb), cb.o);
+            }
+            int added = 0;
+            if (res2 != 0) {
+                float tv = res2 == 1 ? 1.0f : -1.0f;
+                if (cb.turn == 1)
+                    tv = -tv;
+                if (l == 0)
+                    P.node_info[nbase + cid] = make_uint4(0u, (u32)res2 << 16, 0u, f2u(tv));
+                kind = AZH_LEAF_TERMINAL;
+            } else if (known != NONE) {
+                // same position, same moves in the same order: take the priors and the value, no evaluation
+                const uint4 kinfo = P.node_info[nbase + known];
+                for (int j = l; j < M2; j += HL) {
+                    ed[nf + j] = fresh_edge(ed[kinfo.x + j].x);
+                    P.edge_move[ebase + nf + j] = s_moves[j];
+                }
+                added = M2;
+                if (l == 0)
+                    P.node_info[nbase + cid] = make_uint4(nf, (u32)M2, 0u, kinfo.w);
+                kind = AZH_LEAF_TERMINAL;  // "value known": backed up from node_info.w like a finished position
+                flags |= 2u;
+                st_newmoves = (u32)M2;
+            } else {
+                for (int j = l; j < M2; j += HL) {
+                    ed[nf + j] = fresh_edge(0u);
+                    P.edge_move[ebase + nf + j] = s_moves[j];
+                }
+                added = M2;
+                if (l == 0)
+                    P.node_info[nbase + cid] = make_uint4(nf, (u32)M2, 0u, 0u);
+                kind = AZH_LEAF_EVAL;
+                st_newmoves = (u32)M2;
+            }
+            if (l == 0) {
+                P.node_board[nbase + cid] = make_ulonglong2(pack_word0(cb), cb.o);
+                // the edge gets its child and the child's range
+                reinterpret_cast<uint2 *>(ed + eidx)[1] =
+                    make_uint2(cid << 16, res2 != 0 ? pack_kid(0u, 0u, 1u) : pack_kid(nf, (u32)M2, 0u));
+                *reinterpret_cast<int2 *>(&gs->n_nodes) = make_int2(counts.x + 1, counts.y + added);
+                P.leaf_board[g] = cb.turn ? make_ulonglong2(cb.o, cb.x) : make_ulonglong2(cb.x, cb.o);
+            }
+            leaf_node = (int)cid;
+        }
+    } else if (s.phase == 1 && l == 0) {
+        P.leaf_board[g] = make_ulonglong2(0ull, 0ull);   // parked, or ended at a finished position
+    }
+    if (s.phase == 1) {
         // the path entries of this launch (none after an overflow: depth is 0 then)
         const int left = depth - path_base;
         if (l < left)
@@ -411,6 +375,10 @@ __device__ inline int select_game_h(const EngineParams &P, int g, const HState &
 // backup_game on 32 lanes (cpp/self_play_client.cpp:204-271 priors + noise, :449-459 backup).  `scratch`: 256 floats of LDS
 // of this game's own (the root's gamma draws wait there for their total: eight interleaved Philox chains in registers cost
 // the whole kernel a wave per SIMD).
+//
+// One instruction stream for both games of the wave, whatever their leaves are: three memory round trips — (1) the leaf's
+// header, the net's value, the path; (2) the leaf's moves and the path's edges; (3) the logits, while the path update is
+// stored — under lane predicates, instead of a branch per kind of leaf that the other game would sit out.
 __device__ inline void backup_game_h(const EngineParams &P, int g, HState &s, float *scratch)
 {
     constexpr int HL = 32, R = MAX_MOVES / HL;  // 8 elements per lane; element j = l + 32 r: virtual lane l + 32 (r & 1)
@@ -421,25 +389,94 @@ __device__ inline void backup_game_h(const EngineParams &P, int g, HState &s, fl
     const u32 slot = (u32)s.arena * (u32)P.G + (u32)g;
     uint4 *const ed = P.edge + (size_t)slot * P.edge_cap;
     uint4 *const ni = P.node_info + (size_t)slot * P.node_cap;
+    const bool priors = kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT;
+    const bool walk = kind == AZH_LEAF_EVAL || kind == AZH_LEAF_TERMINAL;
+    const bool remember = (P.flags & AZH_FLAG_EVAL_CACHE) && kind == AZH_LEAF_EVAL && l == 0;
 
-    if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_ROOT) {
-        const uint4 info = ni[s.leaf_node];
-        const u32 first = info.x;
-        const int M = (int)(info.y & 0xFFFFu);
-        const float *row = P.logits + (size_t)g * AZH_POLICY_SIZE;
-        const u16 *em = P.edge_move + (size_t)slot * P.edge_cap + first;
-        float ex[R];
+    // (1)
+    const uint4 info = ni[s.leaf_node];
+    const float net_value = P.values[g];
+    const int *path = P.path + (size_t)g * P.path_cap;
+    const int plen = walk ? s.path_len : 0;
+    int pe0 = -1, pe1 = -1;
+    if (l < plen)
+        pe0 = path[l];
+    if (l + HL < plen)
+        pe1 = path[l + HL];
+    ulonglong2 leaf_b = make_ulonglong2(0ull, 0ull);
+    if (remember)
+        leaf_b = P.node_board[(size_t)slot * P.node_cap + s.leaf_node];
+
+    // (2)
+    const u32 first = info.x;
+    const int M = priors ? (int)(info.y & 0xFFFFu) : 0;
+    const u16 *em = P.edge_move + (size_t)slot * P.edge_cap + first;
+    u32 mv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = l + HL * r;
+        mv[r] = 0;
+        if (j < M)
+            mv[r] = em[j];
+    }
+    uint2 q0 = make_uint2(0u, 0u), q1 = make_uint2(0u, 0u);   // (total score, visits | child) of this lane's path edges
+    if (pe0 >= 0) {
+        const u32 *e = reinterpret_cast<const u32 *>(ed + pe0);
+        q0 = make_uint2(e[1], e[2]);
+    }
+    if (pe1 >= 0) {
+        const u32 *e = reinterpret_cast<const u32 *>(ed + pe1);
+        q1 = make_uint2(e[1], e[2]);
+    }
+
+    // (3)
+    const float *row = P.logits + (size_t)g * AZH_POLICY_SIZE;
+    float ex[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = l + HL * r;
+        ex[r] = -INFINITY;
+        if (j < M)
+            ex[r] = row[policy_index(mv[r])];
+    }
+    // step() part 4 (:449-459): flip the score at every edge on the way up
+    const float v = kind == AZH_LEAF_EVAL ? net_value : u2f(info.w);
+    const float sc0 = (v + 1.0f) * 0.5f;
+    const float fa = 1.0f - sc0, fb = 1.0f - fa, fc = 1.0f - fb;
+    if (pe0 >= 0) {
+        const int flips = plen - l;
+        const float val = flips == 1 ? fa : ((flips & 1) ? fc : fb);
+        u32 *e = reinterpret_cast<u32 *>(ed + pe0);
+        e[1] = f2u(u2f(q0.x) + val);
+        e[2] = q0.y + 1u;  // visits: the low half of the word (<= 60000, never carries into the child id)
+    }
+    if (pe1 >= 0) {
+        const int flips = plen - (l + HL);
+        const float val = flips == 1 ? fa : ((flips & 1) ? fc : fb);
+        u32 *e = reinterpret_cast<u32 *>(ed + pe1);
+        e[1] = f2u(u2f(q1.x) + val);
+        e[2] = q1.y + 1u;
+    }
+    for (int i = 2 * HL + l; i < plen; i += HL) {   // (paths longer than 64 edges: the rest, a round trip per 32)
+        const int flips = plen - i;
+        const float val = flips == 1 ? fa : ((flips & 1) ? fc : fb);
+        u32 *e = reinterpret_cast<u32 *>(ed + path[i]);
+        e[1] = f2u(u2f(e[1]) + val);
+        e[2] += 1u;  // visits: the low half of the word (<= 60000, never carries into the child id)
+    }
+    if (remember) {
+        // the leaf now carries an evaluation: remember its value and enter it in the table
+        reinterpret_cast<u32 *>(ni + s.leaf_node)[3] = f2u(net_value);
+        tt_insert(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, leaf_b.x, leaf_b.y, (u32)s.leaf_node);
+    }
+
+    if (priors) {
+        // Evaluations::populate (:204-271): softmax over the legal moves' logits, then the Dirichlet mix at the root
         float mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int j = l + HL * r;
-            ex[r] = -INFINITY;
-            if (j < M) {
-                ex[r] = row[policy_index(em[j])];
-                if (ex[r] > mx)
-                    mx = ex[r];
-            }
-        }
+        for (int r = 0; r < R; r++)
+            if (l + HL * r < M && ex[r] > mx)
+                mx = ex[r];
         mx = hw::max_f32(mx);
         float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
@@ -491,29 +528,8 @@ __device__ inline void backup_game_h(const EngineParams &P, int g, HState &s, fl
                 reinterpret_cast<u32 *>(ed + first + j)[0] = f2u(ex[r]);
         }
     }
-
-    if ((P.flags & AZH_FLAG_EVAL_CACHE) && kind == AZH_LEAF_EVAL) {
-        if (l == 0) {
-            reinterpret_cast<u32 *>(ni + s.leaf_node)[3] = f2u(P.values[g]);
-            const ulonglong2 b = P.node_board[(size_t)slot * P.node_cap + s.leaf_node];
-            tt_insert(tt_of(P, s.arena, g), (u32)P.tt_size - 1u, b.x, b.y, (u32)s.leaf_node);
-        }
-    }
-    if (kind == AZH_LEAF_EVAL || kind == AZH_LEAF_TERMINAL) {
-        const float v = kind == AZH_LEAF_EVAL ? P.values[g] : u2f(ni[s.leaf_node].w);
-        const float sc0 = (v + 1.0f) * 0.5f;
-        const float fa = 1.0f - sc0, fb = 1.0f - fa, fc = 1.0f - fb;
-        const int *path = P.path + (size_t)g * P.path_cap;
-        for (int i = l; i < s.path_len; i += HL) {
-            const int flips = s.path_len - i;
-            const float val = flips == 1 ? fa : ((flips & 1) ? fc : fb);
-            u32 *e = reinterpret_cast<u32 *>(ed + path[i]);
-            e[1] = f2u(u2f(e[1]) + val);
-            e[2] += 1u;
-        }
-        if (s.path_len > 0)
-            s.root_visits += 1;
-    }
+    if (walk && s.path_len > 0)
+        s.root_visits += 1;
     if (kind == AZH_LEAF_ROOT)
         s.phase = 1;
     s.leaf_kind = AZH_LEAF_NONE;
