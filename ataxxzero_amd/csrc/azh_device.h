@@ -297,184 +297,6 @@ __device__ inline int wave_movegen(const Board &b, u64 blockers, u16 *moves, int
     return total;
 }
 
-// ---------------------------------------------------------------- half-wave (32 lanes per game) helpers
-//
-// Beyond 8192 games the one-wave-per-game kernel runs its games in rounds (a CU holds 32 waves), and the tree launch
-// lasts as long as the deepest descent of its LAST round.  The half-wave kernels put two games in a wave, 32 lanes each,
-// so twice as many descents are in flight per wave slot.  Everything a game keeps is then per-lane data that happens to
-// be equal across its 32 lanes (the compiler sees ordinary divergent values: no scalar registers, no v_readlane with a
-// scalar lane id), and the two games of a wave take different paths under the EXEC mask.
-//
-// The engine/oracle contract fixes the ORDER of every f32 sum over a node's moves: element j sits in "virtual lane"
-// j % 64 (round j / 64), a lane adds its rounds in order, and the 64 partial sums are combined by the xor butterfly
-// 1, 2, 4, 8, 16, 32 (wave_sum_f32).  A half-wave lane l holds virtual lanes l AND l + 32 (partials p0, p1): the
-// butterfly steps 1..16 pair lanes inside a group of 32 and run on p0 and p1 separately, and the xor-32 step is the
-// in-lane add p0 + p1 — the same additions on the same operands (IEEE addition is commutative), so the same bits.
-namespace hw {
-
-__device__ inline int lane() { return (int)(threadIdx.x & 31); }   // lane within the game
-__device__ inline int half() { return (int)((threadIdx.x >> 5) & 1); }
-
-// my game's 32 bits of a wave ballot
-__device__ inline u32 ballot(bool p)
-{
-    const u64 m = __ballot(p);
-    return half() ? (u32)(m >> 32) : (u32)m;
-}
-
-// value of lane `src` (0..31, the same in all lanes of the game) of my game: each game's index and value through scalar
-// registers (v_readlane ignores EXEC, so this also works while the other game of the wave sits out a branch — what it reads
-// for that game is then unused).  (The first version went through the LDS crossbar — ds_bpermute_b32 — and paid its latency
-// five times per tree level, in series: profiles/round4_halfwave_first_version_stamps.txt.)
-__device__ inline int read_lane(int v, int src)
-{
-    const int s0 = __builtin_amdgcn_readlane(src, 0), s1 = __builtin_amdgcn_readlane(src, 32);
-    const int a = __builtin_amdgcn_readlane(v, s0), b = __builtin_amdgcn_readlane(v, s1 + 32);
-    return (threadIdx.x & 32) ? b : a;
-}
-
-// value of lane 31 of my game
-__device__ inline int last_lane(int v)
-{
-    const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
-    return (threadIdx.x & 32) ? b : a;
-}
-
-// rows 0 <-> 1 (and 2 <-> 3) exchanged lane for lane: gfx950's v_permlane16_swap
-__device__ inline int other_row(int v)
-{
-    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-    // r[0] = rows {0, 0, 2, 2}, r[1] = rows {1, 1, 3, 3} of v: in every lane one of the two is v itself, the other one
-    // the other row's value (whichever order the pair comes back in)
-    return (int)(r[0] ^ r[1] ^ (unsigned)v);
-}
-
-// reductions over the game's 32 lanes, result in every lane
-__device__ inline float sum_tree_f32(float v)
-{
-    v = v + __int_as_float(dpp_i32<0xB1>(0, __float_as_int(v)));    // xor 1
-    v = v + __int_as_float(dpp_i32<0x4E>(0, __float_as_int(v)));    // xor 2
-    v = v + __int_as_float(dpp_i32<0x141>(0, __float_as_int(v)));   // the other quad of the 8 (row_half_mirror)
-    v = v + __int_as_float(dpp_i32<0x140>(0, __float_as_int(v)));   // the other 8 of the row (row_mirror)
-    return v + __int_as_float(other_row(__float_as_int(v)));        // xor 16
-}
-
-// the canonical sum over 64 virtual lanes: p0 = this lane's partial for virtual lane l, p1 for l + 32
-__device__ inline float sum_f32(float p0, float p1) { return sum_tree_f32(p0) + sum_tree_f32(p1); }
-
-__device__ inline float max_f32(float v)
-{
-    const auto mx = [](float a, float b) { return b > a ? b : a; };
-    v = mx(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v), __float_as_int(v))));
-    v = mx(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v), __float_as_int(v))));
-    v = mx(v, __int_as_float(dpp_i32<0x141>(__float_as_int(v), __float_as_int(v))));
-    v = mx(v, __int_as_float(dpp_i32<0x140>(__float_as_int(v), __float_as_int(v))));
-    return mx(v, __int_as_float(other_row(__float_as_int(v))));
-}
-
-__device__ inline u32 max_u32(u32 v)
-{
-    const auto mx = [](u32 a, u32 b) { return b > a ? b : a; };
-    v = mx(v, (u32)dpp_i32<0xB1>((int)v, (int)v));
-    v = mx(v, (u32)dpp_i32<0x4E>((int)v, (int)v));
-    v = mx(v, (u32)dpp_i32<0x141>((int)v, (int)v));
-    v = mx(v, (u32)dpp_i32<0x140>((int)v, (int)v));
-    return mx(v, (u32)other_row((int)v));
-}
-
-__device__ inline u64 max_u64(u64 v)
-{
-    const auto step = [](u64 a, u32 lo, u32 hi) { const u64 o = ((u64)hi << 32) | lo; return o > a ? o : a; };
-    v = step(v, (u32)dpp_i32<0xB1>((int)(u32)v, (int)(u32)v), (u32)dpp_i32<0xB1>((int)(u32)(v >> 32), (int)(u32)(v >> 32)));
-    v = step(v, (u32)dpp_i32<0x4E>((int)(u32)v, (int)(u32)v), (u32)dpp_i32<0x4E>((int)(u32)(v >> 32), (int)(u32)(v >> 32)));
-    v = step(v, (u32)dpp_i32<0x141>((int)(u32)v, (int)(u32)v), (u32)dpp_i32<0x141>((int)(u32)(v >> 32), (int)(u32)(v >> 32)));
-    v = step(v, (u32)dpp_i32<0x140>((int)(u32)v, (int)(u32)v), (u32)dpp_i32<0x140>((int)(u32)(v >> 32), (int)(u32)(v >> 32)));
-    return step(v, (u32)other_row((int)(u32)v), (u32)other_row((int)(u32)(v >> 32)));
-}
-
-__device__ inline u32 sum_u32(u32 v)
-{
-    v += (u32)dpp_i32<0xB1>(0, (int)v);
-    v += (u32)dpp_i32<0x4E>(0, (int)v);
-    v += (u32)dpp_i32<0x141>(0, (int)v);
-    v += (u32)dpp_i32<0x140>(0, (int)v);
-    return v + (u32)other_row((int)v);
-}
-
-// inclusive prefix sum over the game's 32 lanes
-__device__ inline int incl_scan(int v)
-{
-    v += dpp_i32<0x111>(0, v);          // row_shr:1
-    v += dpp_i32<0x112>(0, v);
-    v += dpp_i32<0x114>(0, v);
-    v += dpp_i32<0x118>(0, v);          // inclusive within each row of 16
-    v += dpp_i32<0x142, 0xA>(0, v);     // row_bcast15 into rows 1 and 3: lane 15 -> lanes 16..31, lane 47 -> 48..63
-    return v;
-}
-
-__device__ inline int bcast_last(int v) { return last_lane(v); }
-
-// what a game's lanes hand each other through LDS or memory (see wave_sync above; the two games of a wave never share data)
-__device__ inline void sync() { wave_sync(); }
-
-// Wave-cooperative move generation for one position on 32 lanes: lane l owns squares l and l + 32 (< 49).  Same move
-// order and the same adjudication as wave_movegen.
-__device__ inline int movegen(const Board &b, u64 blockers, u16 *moves, int *result)
-{
-    const int l = lane();
-    const u64 own = b.turn ? b.o : b.x;
-    const u64 empty = BOARD_MASK & ~(b.x | b.o | blockers);
-    const int sq1 = l + 32;
-    u64 t0 = ((own >> l) & 1ULL) ? (double_jump_bb(1ULL << l) & empty) : 0ULL;
-    u64 t1 = (sq1 < 49 && ((own >> sq1) & 1ULL)) ? (double_jump_bb(1ULL << sq1) & empty) : 0ULL;
-    const int c0 = __popcll(t0), c1 = __popcll(t1);
-    const int i0 = incl_scan(c0), i1 = incl_scan(c1);
-    const int tot0 = bcast_last(i0);
-    const int jumps = tot0 + bcast_last(i1);
-    const u64 clones = single_jump_bb(own) & empty;
-    int total = jumps + __popcll(clones);
-    if (moves) {
-        int pos = i0 - c0;
-        while (t0) {
-            const int to = __ffsll((long long)t0) - 1;
-            moves[pos++] = (u16)(l | (to << 8));
-            t0 &= t0 - 1;
-        }
-        pos = tot0 + i1 - c1;
-        while (t1) {
-            const int to = __ffsll((long long)t1) - 1;
-            moves[pos++] = (u16)(sq1 | (to << 8));
-            t1 &= t1 - 1;
-        }
-        if ((clones >> l) & 1ULL)
-            moves[jumps + __popcll(clones & ((1ULL << l) - 1ULL))] = (u16)(l | (l << 8));
-        if (sq1 < 49 && ((clones >> sq1) & 1ULL))
-            moves[jumps + __popcll(clones & ((1ULL << sq1) - 1ULL))] = (u16)(sq1 | (sq1 << 8));
-    }
-    if (result) {
-        int p1 = __popcll(b.x), p2 = __popcll(b.o);
-        const int bl = __popcll(blockers);
-        const int emp = 49 - p1 - p2 - bl;
-        int res = 0;
-        if (p1 == 0) res = 2;
-        else if (p2 == 0) res = 1;
-        else {
-            if (total == 0) {
-                if (b.turn == 0) p2 += emp;
-                else p1 += emp;
-            }
-            if (p1 + p2 + bl == 49)
-                res = p1 < p2 ? 2 : 1;
-        }
-        *result = res;
-        if (p1 == 0 || p2 == 0)
-            total = 0;  // the reference adjudicates before generating moves
-    }
-    return total;
-}
-
-}  // namespace hw
-
 // ---------------------------------------------------------------- deterministic math
 
 __host__ __device__ inline float u2f(u32 u)

@@ -1447,8 +1447,6 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
         compact_leaves<TREE_WAVES>(P, two, s_cnt);
 }
 
-#include "tree_halfwave.h"  // the same phases with two games per wave (32 lanes each), for more than 8192 games
-
 // Reference feature rows for the dense leaf list (cpp/self_play_client.cpp:174-202).
 __global__ void k_features(const ulonglong2 *boards, const int *list, int n, u64 blockers, float *out)
 {
@@ -1532,10 +1530,6 @@ struct azh_engine {
     bool selected = false;
     bool arena_lists = false;  // run_arena: one leaf list per net
     bool stamp_next = false;   // azh_engine_tree_stamps: the next fused tree launch of the loop is the stamped instantiation
-    // lanes per game in the tree kernels: 64 (one wave per game) up to TREE_ONE_ROUND_GAMES games, 32 (two games per wave,
-    // tree_halfwave.h) beyond, where one wave per game no longer fits the chip's wave slots at once.  The arena's flags
-    // keep 64.  AZH_TREE_LANES=32|64 in the environment overrides the choice (tests run both on the same games).
-    int lanes = WAVE;
 };
 
 static const size_t MAX_TIMED_SAMPLES = 8192;
@@ -1584,17 +1578,6 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     P.start_turn = cfg->start_turn;
     P.flags = cfg->flags;
     P.select_budget = (int)cfg->select_budget;
-
-    e->lanes = P.G > TREE_ONE_ROUND_GAMES ? 32 : WAVE;
-    if (const char *env = getenv("AZH_TREE_LANES")) {
-        if (strcmp(env, "32") && strcmp(env, "64")) {
-            delete e;
-            return azh_fail(-2, "azh_engine_create: AZH_TREE_LANES must be 32 or 64, not '%s'", env);
-        }
-        e->lanes = atoi(env);
-    }
-    if (cfg->flags & (AZH_FLAG_PY_POSTERIOR | AZH_FLAG_TWO_NETS))
-        e->lanes = WAVE;  // the arena's posterior and its two leaf lists exist on 64 lanes only
 
     const size_t G = (size_t)P.G;
     // ring of finished-game records (64 KiB per slot between two drains)
@@ -1705,10 +1688,7 @@ static int enqueue_advance(azh_engine *e, hipStream_t stream, hipEvent_t done = 
 
 static int enqueue_select(azh_engine *e)
 {
-    if (e->lanes == 32)
-        hipLaunchKernelGGL(k_select_h, dim3((e->P.G + 1) / 2), dim3(WAVE), 0, e->stream, e->P);
-    else
-        hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
+    hipLaunchKernelGGL(k_select, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
     if (enqueue_compact(e))
         return -1;
     return enqueue_advance(e, e->stream);
@@ -1716,13 +1696,8 @@ static int enqueue_select(azh_engine *e)
 
 static int enqueue_backup(azh_engine *e)
 {
-    if (e->lanes == 32) {
-        hipLaunchKernelGGL(k_backup_h, dim3((e->P.G + 1) / 2), dim3(WAVE), 0, e->stream, e->P);
-        hipLaunchKernelGGL(k_mark_h, dim3((e->P.G + 1) / 2), dim3(WAVE), 0, e->stream, e->P);
-    } else {
-        hipLaunchKernelGGL(k_backup, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
-        hipLaunchKernelGGL(k_mark, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
-    }
+    hipLaunchKernelGGL(k_backup, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
+    hipLaunchKernelGGL(k_mark, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P);
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -1839,14 +1814,6 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
     const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
     // one fused tree launch; ev (or nullptr) is signalled by the kernel's own completion
     auto launch_tree = [&](bool stamped, int mode, hipEvent_t ev) {
-        if (e->lanes == 32) {   // two games per wave, one wave per workgroup
-            const dim3 grid((e->P.G + 1) / 2), block(WAVE);
-            if (stamped)
-                hipExtLaunchKernelGGL((k_tree_h<true, 1>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode);
-            else
-                hipExtLaunchKernelGGL((k_tree_h<false, 1>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode);
-            return;
-        }
         const bool small = e->P.G <= TREE_ONE_ROUND_GAMES;
         const int waves = small ? TREE_WAVES_SMALL : TREE_WAVES_LARGE;
         const dim3 grid((e->P.G + waves - 1) / waves), block(waves * WAVE);

@@ -14,15 +14,6 @@ from tests.helpers import replay_game_entry, synthetic_evals
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[64, 32], ids=["wave-per-game", "two-games-per-wave"])
-def lanes(request, monkeypatch):
-    """Both tree-kernel families on the same games: one wave per game (the default up to 8192 games) and two games per
-    wave, 32 lanes each (csrc/tree_halfwave.h, the default beyond) — AZH_TREE_LANES is read when an engine is created.
-    The oracle is the same for both: the half-wave kernels keep the 64-lane order of every f32 sum."""
-    monkeypatch.setenv("AZH_TREE_LANES", str(request.param))
-    return request.param
-
-
 def make_pair(games, visits, max_plies=400, edges_per_node=96, seed=77, fen=orc.START_FEN_SELFPLAY, weight=0.25,
               flags=0, select_budget=0):
     ocfg = orc.make_config(games, visits, seed=seed, fen_str=fen, max_plies=max_plies,
@@ -61,7 +52,7 @@ def run_lockstep(oe, ge, iterations, check_every=1, evaluator=synthetic_evals):
     return o_games, g_lines
 
 
-def test_engine_matches_oracle_bit_for_bit_small_visits(lanes):
+def test_engine_matches_oracle_bit_for_bit_small_visits():
     oe, ge = make_pair(games=24, visits=12, max_plies=60, seed=5)
     o_games, g_lines = run_lockstep(oe, ge, 900, check_every=7)
     so, sg = oe.stats(), ge.stats()
@@ -78,14 +69,14 @@ def test_engine_matches_oracle_bit_for_bit_small_visits(lanes):
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
 
 
-def test_engine_matches_oracle_reference_settings(lanes):
+def test_engine_matches_oracle_reference_settings():
     # the reference's constants: 4-blocker start, Dirichlet 0.15 / 0.25, c = 1
     oe, ge = make_pair(games=6, visits=100, seed=20260101)
     run_lockstep(oe, ge, 450, check_every=50)
     assert oe.stats()["plies"] >= 6
 
 
-def test_edge_arena_overflow_forces_the_move_like_the_oracle(lanes):
+def test_edge_arena_overflow_forces_the_move_like_the_oracle():
     oe, ge = make_pair(games=4, visits=64, edges_per_node=8, seed=9, fen=orc.START_FEN_PLAIN)
     run_lockstep(oe, ge, 300, check_every=10)
     assert oe.stats()["edge_overflow"] > 0 and ge.stats()["edge_overflow"] == oe.stats()["edge_overflow"]
@@ -207,7 +198,7 @@ def test_game_limit_plays_exactly_the_games_below_it_and_then_idles():
         limited.set_game_limit(0)
 
 
-def test_game_limit_matches_oracle_in_lockstep(lanes):
+def test_game_limit_matches_oracle_in_lockstep():
     # the same rule in the oracle (orc_engine_set_game_limit): slots idle at the same iteration, states and trees equal
     oe, ge = make_pair(games=12, visits=6, max_plies=90, seed=4)
     oe.set_game_limit(30)
@@ -230,7 +221,7 @@ def test_game_limit_matches_oracle_in_lockstep(lanes):
     assert so["games"] + so["dropped"] == 30 + more and len(g2) == len(o2) and all(ge.game_state(g).phase == 3 for g in range(12))
 
 
-def test_reroot_queue_spill_path_matches_oracle(lanes):
+def test_reroot_queue_spill_path_matches_oracle():
     # visits > 512: kept subtrees grow past the LDS part of the re-root frontier queue, so the
     # HBM spill path of advance_game is exercised; still bit-exact against the oracle
     # (a steep prior over the policy index concentrates the visits on one line, so most of the tree is kept)
@@ -254,7 +245,7 @@ def test_odd_sizes_and_f16_device_loop():
         ge.close()
 
 
-def test_one_random_move_variant_matches_oracle(lanes):
+def test_one_random_move_variant_matches_oracle():
     # cpp/self_play_client.cpp:515-552 (ONE_RANDOM_MOVE build): entries carry "random_ply"
     oe, ge = make_pair(games=32, visits=8, max_plies=240, seed=11, flags=orc.FLAG_ONE_RANDOM_MOVE)
     assert link.FLAG_ONE_RANDOM_MOVE == orc.FLAG_ONE_RANDOM_MOVE
@@ -307,7 +298,7 @@ def test_symmetry_averaging_flag_in_the_device_loop_equals_host_evaluated_search
     assert dev.stats()["plies"] == host.stats()["plies"] > 9
 
 
-def test_parked_descents_match_oracle_and_leave_every_game_unchanged(lanes):
+def test_parked_descents_match_oracle_and_leave_every_game_unchanged():
     # select_budget: a descent deeper than the budget parks and resumes next iteration.  Lockstep parity with the
     # oracle's same rule, and the games written are exactly the games of the unbudgeted engine.
     oe, ge = make_pair(games=16, visits=12, max_plies=300, seed=21, select_budget=2)
@@ -424,21 +415,14 @@ def _oracle_follow(oe, net, blockers, iterations):
     ("C2-shape", 192, 200, 12, 400, 48, 4, 150),     # BASELINE configs[1]: 12x128 net, 200 sims/move
     ("C4-shape", 48, 800, 8, 400, 48, 4, 450),       # BASELINE configs[3]: 8x128 net, 800 sims/move, node_cap 808
     ("bench-size", 4096, 400, 12, 400, 48, 3, 150),  # bench.py's workload: 4096 games, 400 sims/move, 12x128
-    ("two-rounds", 8203, 8, 1, 60, 6, 2, 40),        # more games than fit the chip's wave slots one wave each (8192): two games
-                                                     # per wave (32 lanes each), a ragged last wave, a need-bit mask with a ragged last word
-    ("two-rounds-64-lanes", 8203, 8, 1, 60, 6, 2, 40),   # the same with one wave per game, in two rounds
-    ("turnover-32-lanes", 512, 12, 2, 90, 6, 12, 250),
-    ("budget48-32-lanes", 511, 100, 2, 400, 48, 6, 100),  # (an odd number of games: the last wave holds one)
-    ("C2-shape-32-lanes", 192, 200, 12, 400, 48, 4, 150),
+    ("two-rounds", 8203, 8, 1, 60, 6, 2, 40),        # more games than resident waves (8192): one game per workgroup,
+                                                     # a need-bit mask with a ragged last word
 ])
-def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, blocks, max_plies, budget, chunks, chunk, monkeypatch):
+def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, blocks, max_plies, budget, chunks, chunk):
     """The loop bench.py and the CLI run — azh_engine_run: fused k_tree, queued re-roots on the side stream behind
     events, parked descents — against the oracle, iteration for iteration: every game state, every arena word and every
     JSON line.  (The step-wise API the other lock-step tests drive shares the device functions but not the launch
     structure or the stream ordering.)"""
-    if name.endswith("-lanes"):
-        monkeypatch.setenv("AZH_TREE_LANES", name.split("-")[-2])
-        name = name.rsplit("-", 2)[0]
     conv, bn = model.random_init(blocks, 128, seed=7)
     net = link.Net(conv, bn)
     oe, ge = make_pair(games=games, visits=visits, max_plies=max_plies, seed=99, select_budget=budget)
@@ -526,7 +510,7 @@ def test_lost_records_do_not_stall_uid_ordered_emission():
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
 
 
-def test_loaded_positions_hook_matches_oracle(lanes):
+def test_loaded_positions_hook_matches_oracle():
     # azh_engine_set_positions (bench.py's steady-state set-up): every slot restarts at a mid-game position and ply; those
     # games are played and counted but not written; the slot's next game is an ordinary one
     oe, ge = make_pair(games=24, visits=10, max_plies=200, seed=8)
@@ -553,7 +537,7 @@ def test_loaded_positions_hook_matches_oracle(lanes):
         ge2.set_positions(boards, np.full(24, 200, np.int32))       # ply beyond max_plies
 
 
-def test_evaluation_cache_through_game_turnover_matches_oracle(lanes):
+def test_evaluation_cache_through_game_turnover_matches_oracle():
     # many plies, finished and cut games, slots restarting: the table is cleared / rebuilt at every one of those events
     conv, bn = model.random_init(2, 128, seed=7)
     net = link.Net(conv, bn)
@@ -574,7 +558,7 @@ def test_evaluation_cache_through_game_turnover_matches_oracle(lanes):
     assert written > 40 and so["dropped"] > 0 and so["cache_hits"] > 0 and so["reroot_nodes"] > so["plies"]
 
 
-def test_evaluation_cache_matches_oracle_and_saves_evaluations(lanes):
+def test_evaluation_cache_matches_oracle_and_saves_evaluations():
     """AZH_FLAG_EVAL_CACHE in the device-resident loop against the oracle's same rule, f32 tower on both sides (so an
     evaluation taken from the cache is bit for bit what the net would return): states, trees, game lines and counters;
     and against the uncached engine: the same games, fewer evaluations."""
