@@ -5,8 +5,10 @@
 // for ONE workgroup per CU).
 //
 // One workgroup = 4 waves = 3 boards = 48 tiles of 2x2 outputs, as the design on paper ("Winograd, priced"):
-//   LDS   activations [2][147 cells][16 units of 8 channels] f16 (75 KB, as the direct tower) + V [4 positions][48 tiles]
-//         [16 units] f16 (48 KB): the transformed input of ONE row group of the 4x4 positions — all sixteen are 196 KB
+//   LDS   activations [2][16 units of 8 channels][160 slots] f16 (80 KB, the direct tower's image) + V [4 positions][16 units]
+//         [48 tiles] f16 (48 KB): the transformed input of ONE row group of the 4x4 positions — all sixteen are 196 KB.
+//         (Lay-outs chosen so that a B fragment's 16 lanes read 256 contiguous bytes and the transform writes contiguous
+//         tiles; with the tile-major lay-out of a first attempt the same mix ran 16-way bank-conflicted.)
 //   per layer, four passes (row group a = 0..3 of the 4x4 transform):
 //     transform  every lane takes 3 (tile, unit) items: 8 ds_read_b128 (two rows of the 4x4 patch), 32 v_pk_add_f16
 //                (t_j = d[i1][j] +- d[i2][j]; V_b = t_j1 +- t_j2), 4 ds_write_b128 (positions (a, 0..3))
@@ -111,27 +113,40 @@ __global__ __launch_bounds__(256) void k_wino(const uint4 *__restrict__ U, int l
                     V[(b * UNITS + unit) * TILES + tile] = vb[b].u;
             }
             __syncthreads();
-            // ---- products: 4 positions x 4 k-steps x (2 oc tiles x 3 tile tiles)
+            // ---- products: 4 positions x 4 k-steps x (2 oc tiles x 3 tile tiles); the A fragments (U, from L2) are requested
+            // two steps ahead in a register ring, the B fragments (V, from LDS) one step ahead — as the direct tower's k-loop does
             f4 M[4][6];
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
+            for (int b = 0; b < 4; b++)
 #pragma unroll
                 for (int u = 0; u < 6; u++)
                     M[b][u] = f4{0.f, 0.f, 0.f, 0.f};
+            U4H A[3][2], B[2][3];
+            auto load_a = [&](int step, U4H *dst) {
+                const int pos = a * 4 + (step >> 2), ks = step & 3;
+                dst[0].u = Ul[((pos * 8 + 2 * w) * 4 + ks) * 64 + lane];
+                dst[1].u = Ul[((pos * 8 + 2 * w + 1) * 4 + ks) * 64 + lane];
+            };
+            auto load_b = [&](int step, U4H *dst) {
+                const int b = step >> 2, ks = step & 3;
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    U4H A0, A1, B[3];
-                    const int pos = a * 4 + b;
-                    A0.u = Ul[((pos * 8 + 2 * w) * 4 + ks) * 64 + lane];
-                    A1.u = Ul[((pos * 8 + 2 * w + 1) * 4 + ks) * 64 + lane];
+                for (int tt = 0; tt < 3; tt++)
+                    dst[tt].u = V[(b * UNITS + ks * 4 + (lane >> 4)) * TILES + tt * 16 + (lane & 15)];
+            };
+            load_a(0, A[0]);
+            load_a(1, A[1]);
+            load_b(0, B[0]);
 #pragma unroll
-                    for (int tt = 0; tt < 3; tt++)
-                        B[tt].u = V[(b * UNITS + ks * 4 + (lane >> 4)) * TILES + tt * 16 + (lane & 15)];
+            for (int step = 0; step < 16; step++) {
+                if (step + 2 < 16)
+                    load_a(step + 2, A[(step + 2) % 3]);
+                if (step + 1 < 16)
+                    load_b(step + 1, B[(step + 1) & 1]);
+                const int b = step >> 2;
 #pragma unroll
-                    for (int tt = 0; tt < 3; tt++) {
-                        M[b][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0.h, B[tt].h, M[b][tt], 0, 0, 0);
-                        M[b][3 + tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1.h, B[tt].h, M[b][3 + tt], 0, 0, 0);
-                    }
+                for (int tt = 0; tt < 3; tt++) {
+                    M[b][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[step % 3][0].h, B[step & 1][tt].h, M[b][tt], 0, 0, 0);
+                    M[b][3 + tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[step % 3][1].h, B[step & 1][tt].h, M[b][3 + tt], 0, 0, 0);
                 }
             }
             // ---- fold row group a of A^T M A into the 2x2 outputs
