@@ -119,7 +119,8 @@ def test_match_from_random_openings(tmp_path):
             assert orc.result(p) == 0 and mv in [orc.move_string(x) for x in orc.movegen(p)], (uid, mv)
             c = orc.move_from_string(mv)
             orc.lib().orc_makemove(p, c & 0xFF, c >> 8)
-        assert orc.result(p) == g["result"] != 0
+        assert orc.result(p) == g["result"]
+        assert g["result"] != 0 or len(g["moves"]) == 400          # (a game cut at the ply limit is annulled, opening plies included)
         x, o = g["final_score"]
         cells = [int(v) for v in orc.board_cells(p)]
         assert (cells.count(1), cells.count(2)) == (x, o)

@@ -48,7 +48,7 @@ union U4H {
     h2 p[4];
 };
 
-__global__ __launch_bounds__(256) void k_wino(const uint4 *__restrict__ U, int layers, int boards, float *sink)
+__global__ __launch_bounds__(256) void k_wino(const uint4 *__restrict__ U, int layers, int boards, float *sink, int phases)
 {
     extern __shared__ uint4 lds[];
     uint4 *act = lds;                // [2][16 units][160 slots]
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void k_wino(const uint4 *__restrict__ U, int l
         const uint4 *src = act + cur * ACT_U4;
         for (int a = 0; a < 4; a++) {
             // ---- input transform of row group a: 3 (tile, unit) items per lane
+            if (phases & 1)
 #pragma unroll
             for (int it = 0; it < 3; it++) {
                 const int item = t + 256 * it;          // 0..767: consecutive lanes take consecutive tiles of one unit
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256) void k_wino(const uint4 *__restrict__ U, int l
                 for (int tt = 0; tt < 3; tt++)
                     dst[tt].u = V[(b * UNITS + ks * 4 + (lane >> 4)) * TILES + tt * 16 + (lane & 15)];
             };
+            if (phases & 2) {
             load_a(0, A[0]);
             load_a(1, A[1]);
             load_b(0, B[0]);
@@ -149,7 +151,9 @@ __global__ __launch_bounds__(256) void k_wino(const uint4 *__restrict__ U, int l
                     M[b][3 + tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[step % 3][1].h, B[step & 1][tt].h, M[b][3 + tt], 0, 0, 0);
                 }
             }
+            }
             // ---- fold row group a of A^T M A into the 2x2 outputs
+            if (phases & 4)
 #pragma unroll
             for (int u = 0; u < 6; u++) {
                 const f4 r0 = M[0][u] + M[1][u] + M[2][u];
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(256) void k_wino(const uint4 *__restrict__ U, int l
         }
         // ---- epilogue: relu, convert, write the other activation image (8-byte runs of four channels, as the direct tower)
         uint4 *dst = act + (1 - cur) * ACT_U4;
+        if (phases & 8)
 #pragma unroll
         for (int u = 0; u < 6; u++)
 #pragma unroll
@@ -226,28 +231,33 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int r = 0; r < 3; r++)
-        hipLaunchKernelGGL(k_wino, dim3(wgs), dim3(256), LDS_BYTES, 0, (const uint4 *)dU, layers, boards, dS);
-    CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; r++)
-        hipLaunchKernelGGL(k_wino, dim3(wgs), dim3(256), LDS_BYTES, 0, (const uint4 *)dU, layers, boards, dS);
-    CK(hipEventRecord(e1));
-    CK(hipEventSynchronize(e1));
-    float ms;
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    ms /= reps;
-    const double rounds = (double)wgs / 256.0;   // one workgroup per CU (124 KB of LDS)
-    printf("winograd mix: %d boards = %d workgroups (%.2f rounds of 256), %d layers: %.3f ms per launch; %.2f us per layer and "
-           "workgroup round; U stream %.1f MB; LDS %d bytes per workgroup\n",
-           boards, wgs, rounds, layers, ms, 1e3 * ms / layers / (rounds < 1 ? 1 : rounds), u_count * 16 / 1e6, LDS_BYTES);
-    // one workgroup alone: the per-layer time without the other CUs' L2 traffic
-    CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; r++)
-        hipLaunchKernelGGL(k_wino, dim3(1), dim3(256), LDS_BYTES, 0, (const uint4 *)dU, layers, 3, dS);
-    CK(hipEventRecord(e1));
-    CK(hipEventSynchronize(e1));
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("one workgroup alone: %.2f us per layer\n", 1e3 * ms / reps / layers);
+    struct { int mask; const char *what; } runs[] = {{15, "whole layer"}, {1, "input transform only"}, {2, "products only (fragment loads + MFMAs)"},
+                                                     {4, "output fold only"}, {8, "epilogue only"}, {0, "barriers and loop only"}};
+    for (auto &run : runs) {
+        for (int r = 0; r < 2; r++)
+            hipLaunchKernelGGL(k_wino, dim3(wgs), dim3(256), LDS_BYTES, 0, (const uint4 *)dU, layers, boards, dS, run.mask);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; r++)
+            hipLaunchKernelGGL(k_wino, dim3(wgs), dim3(256), LDS_BYTES, 0, (const uint4 *)dU, layers, boards, dS, run.mask);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        const double rounds = (double)wgs / 256.0;   // one workgroup per CU (128 KB of LDS)
+        // one workgroup alone: the per-layer time without the other CUs' L2 traffic
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; r++)
+            hipLaunchKernelGGL(k_wino, dim3(1), dim3(256), LDS_BYTES, 0, (const uint4 *)dU, layers, 3, dS, run.mask);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms1;
+        CK(hipEventElapsedTime(&ms1, e0, e1));
+        printf("%-42s %d boards = %d workgroups (%.2f rounds of 256), %d layers: %.3f ms per launch, %.2f us per layer and workgroup "
+               "round; one workgroup alone %.2f us per layer\n", run.what, boards, wgs, rounds, layers, ms,
+               1e3 * ms / layers / (rounds < 1 ? 1 : rounds), 1e3 * ms1 / reps / layers);
+    }
+    printf("(U stream %.1f MB, LDS %d bytes per workgroup)\n", u_count * 16 / 1e6, LDS_BYTES);
     return 0;
 }
