@@ -31,7 +31,6 @@ int azh_require_device(void);
 int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                    const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
                    float *d_values, hipStream_t stream, unsigned long long *d_stamps = nullptr);
-int azh_net_round_boards(azh_net *net, int dtype);
 // symmetry-averaged evaluation (nn_evals.py:48-62); scratch: [8 max_n][833] and [8 max_n] floats
 int azh_net_launch_sym(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                        const int *d_count, int max_n, unsigned long long blockers, float *d_tmp_logits,

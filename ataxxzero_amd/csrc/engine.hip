@@ -102,11 +102,6 @@ struct EngineParams {
                        // microsecond: thousands of workgroups finishing together would queue on it)
     u32 *need_mask;    // [2][mask_words] one bit per game: its leaf goes to the net (row 1: to net B, arena); set by
     int mask_words;    // k_tree's workgroups with one atomic OR each, read and cleared by the workgroup that finishes last
-    int eval_round;    // leaves the tower evaluates in one full round of its workgroup slots (azh_engine_set_eval_round;
-                       // 0 = off): a leaf list longer than that is cut to whole rounds, the leaves left over keep their
-                       // mask bit and wait one iteration (compact_leaves)
-    int *defer_cursor; // the compacting thread whose mask words open the (rotated) leaf list: the one that held the first
-                       // leaf left over last time, so that nobody waits twice
     u64 *stamps;       // diagnostic instantiation of k_tree only: [G][TREE_STAMPS] s_memrealtime readings (100 MHz)
     float *logits;
     float *values;
@@ -355,15 +350,6 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
     u64 st_steps = 0, st_evals = 0, st_levels = 0, st_children = 0, st_newmoves = 0, st_cached = 0, st_parked = 0;
     u64 leaf_mover = 0, leaf_opp = 0;
 
-    if (s.leaf_kind == AZH_LEAF_EVAL || s.leaf_kind == AZH_LEAF_ROOT) {
-        // the leaf of the last select has not been evaluated and backed up yet (left over by a whole-rounds leaf list,
-        // azh_engine_set_eval_round, when the device loop stopped): it is asked for again; state, leaf board and
-        // need_eval[g] are as that select left them
-        int need = 1;
-        if (P.flags & AZH_FLAG_TWO_NETS)
-            need = 1 + ((s.ply + g) & 1);
-        return need;
-    }
     if (s.phase >= 2) {
         // 2: the move of this game is due: its re-root runs after this select (k_advance_list), no leaf now
         // 3: the slot is idle (azh_engine_set_game_limit: every game it was to play has been played)
@@ -1326,7 +1312,7 @@ __global__ __launch_bounds__(WAVE) void k_advance_list(EngineParams P)
 // loads on both sides, so no fence is needed (MI355X_MICROARCH.md, hand-off forms).  One kernel and one kernel boundary
 // less per search iteration, and a tail of about a microsecond whatever the number of games.
 template <int TREE_WAVES>
-__device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt /* [2][TREE_WAVES] + 1 */)
+__device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt /* [2][TREE_WAVES] */)
 {
     constexpr int TREE_THREADS = TREE_WAVES * WAVE;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -1353,43 +1339,6 @@ __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt
         b2 += k < w ? s_cnt[TREE_WAVES + k] : 0;
         t1 += s_cnt[k];
         t2 += s_cnt[TREE_WAVES + k];
-    }
-    // Whole rounds for the tower (azh_engine_set_eval_round): the tower's workgroups run in rounds of as many as the
-    // chip holds at once, and a last round that is only partly filled costs most of a full one.  A list longer than a
-    // round is cut to a whole number of rounds; the leaves left over keep their mask bit — their games find it at the
-    // start of the next tree launch, skip that launch and are listed again — and the list is rotated so that it opens
-    // with the words of the thread that held the first leaf left over last time.  Scheduling only: per game the
-    // sequence select -> evaluate -> backup is untouched, the leaf simply waits one iteration.
-    const int R = two ? 0 : P.eval_round;
-    const int quota = (R > 0 && t1 > R) ? (t1 / R) * R : t1;
-    if (quota < t1) {
-        const int cur = __hip_atomic_load(P.defer_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % TREE_THREADS;
-        if (t == cur)
-            s_cnt[2 * TREE_WAVES] = b1;
-        __syncthreads();
-        const int rank0 = s_cnt[2 * TREE_WAVES];
-        for (int k = lo; k < hi; k++) {
-            const u32 m0 = __hip_atomic_load(&m1p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            u32 keep = 0;
-            for (u32 m = m0; m; m &= m - 1) {
-                int pos = b1++ - rank0;
-                pos += pos < 0 ? t1 : 0;
-                const int bit = __ffs((int)m) - 1;
-                if (pos < quota)
-                    P.leaf_list[pos] = 32 * k + bit;
-                else
-                    keep |= 1u << bit;
-                if (pos == quota)
-                    __hip_atomic_store(P.defer_cursor, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (keep != m0)
-                __hip_atomic_store(&m1p[k], keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (t == 0) {
-            *P.leaf_count = quota;
-            __hip_atomic_store(&P.tree_done[TICKET_SHARDS * TICKET_STRIDE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
     }
     for (int k = lo; k < hi; k++) {
         u32 m = __hip_atomic_load(&m1p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1421,7 +1370,7 @@ template <bool STAMP, int TREE_WAVES>
 __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int mode, int two)
 {
     __shared__ u16 s_moves[TREE_WAVES][MAX_MOVES];  // per game: the move list of the node being expanded
-    __shared__ int s_cnt[2 * TREE_WAVES + 1];
+    __shared__ int s_cnt[2 * TREE_WAVES];
     __shared__ int s_need[TREE_WAVES];
     __shared__ int s_last;
     static_assert(32 % TREE_WAVES == 0, "a workgroup's need bits must lie in one word of the mask");
@@ -1433,31 +1382,20 @@ __global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int 
     if (g < P.G) {
         azh_game_state s = P.gs[g];
         const int forced = P.force[g];  // (same round trip as the state)
-        // whole rounds for the tower: a leaf the last compaction left over still has its mask bit (every listed leaf's
-        // bit was cleared, and only this wave's workgroup sets it again, at the end of the launch)
-        u32 left_over = 0;
-        if (P.eval_round != 0)
-            left_over = (__hip_atomic_load(&P.need_mask[g >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (g & 31)) & 1u;
         if constexpr (STAMP) st[1] = tree_stamp();
-        if (left_over != 0 && (s.leaf_kind == AZH_LEAF_EVAL || s.leaf_kind == AZH_LEAF_ROOT)) {
-            // not evaluated yet: nothing to back up, nothing to select — the same leaf is asked for again
-            need = 1;
-            if constexpr (STAMP) st[2] = st[3] = st[4] = st[5] = tree_stamp();
-        } else {
-            if (mode & 1) {
-                backup_game(P, g, s);
-                if constexpr (STAMP) st[2] = tree_stamp();
-                mark_game(P, g, s, forced);
-            }
-            if constexpr (STAMP) {
-                st[3] = tree_stamp();
-                if (!(mode & 1)) st[2] = st[3];
-            }
-            if (mode & 2)
-                need = select_game<STAMP>(P, g, s, s_moves[w], st);  // stores the state
-            else if (lane_id() == 0)
-                P.gs[g] = s;
+        if (mode & 1) {
+            backup_game(P, g, s);
+            if constexpr (STAMP) st[2] = tree_stamp();
+            mark_game(P, g, s, forced);
         }
+        if constexpr (STAMP) {
+            st[3] = tree_stamp();
+            if (!(mode & 1)) st[2] = st[3];
+        }
+        if (mode & 2)
+            need = select_game<STAMP>(P, g, s, s_moves[w], st);  // stores the state
+        else if (lane_id() == 0)
+            P.gs[g] = s;
     }
     if (!(mode & 2))
         return;
@@ -1592,7 +1530,6 @@ struct azh_engine {
     bool selected = false;
     bool arena_lists = false;  // run_arena: one leaf list per net
     bool stamp_next = false;   // azh_engine_tree_stamps: the next fused tree launch of the loop is the stamped instantiation
-    int eval_round = -1;       // azh_engine_set_eval_round: -1 = what the tower holds at once (azh_net_round_boards), 0 = off
 };
 
 static const size_t MAX_TIMED_SAMPLES = 8192;
@@ -1671,7 +1608,6 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
     rc |= dev_alloc(e, &P.tree_done, (size_t)TICKET_SHARDS * TICKET_STRIDE + 1);
     P.mask_words = (P.G + 31) / 32;
     rc |= dev_alloc(e, &P.need_mask, 2 * (size_t)P.mask_words);
-    rc |= dev_alloc(e, &P.defer_cursor, 1);
     rc |= dev_alloc(e, &P.logits, G * AZH_POLICY_SIZE);
     rc |= dev_alloc(e, &P.values, G);
     rc |= dev_alloc(e, &P.rec, G * P.max_plies * REC_STRIDE_WORDS);
@@ -1876,17 +1812,6 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
     if (iterations <= 0)
         return 0;
     const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
-    // whole rounds for the tower (one leaf list only): the round is the tower's to name — boards per workgroup x the
-    // workgroups the chip holds at once, an eighth of that in leaves when every leaf is evaluated in its 8 images
-    e->P.eval_round = 0;
-    if (!(e->P.flags & AZH_FLAG_TWO_NETS)) {
-        int r = e->eval_round >= 0 ? e->eval_round : azh_net_round_boards(net_a, dtype);
-        if (r < 0)
-            return -1;
-        if (e->eval_round < 0 && (e->P.flags & AZH_FLAG_SYMMETRY_AVG))
-            r /= 8;
-        e->P.eval_round = r;
-    }
     // one fused tree launch; ev (or nullptr) is signalled by the kernel's own completion
     auto launch_tree = [&](bool stamped, int mode, hipEvent_t ev) {
         const bool small = e->P.G <= TREE_ONE_ROUND_GAMES;
@@ -2027,27 +1952,6 @@ extern "C" int azh_engine_set_game_limit(azh_engine *e, int64_t games)
     return 0;
 }
 
-// Whole rounds for the tower in the device loop.  leaves < 0 (the default): a leaf list longer than what the tower's
-// workgroups evaluate in one round over the chip (azh_net_round_boards) is cut to whole rounds, the leaves left over wait
-// one iteration; 0: every leaf is evaluated in the iteration that found it; > 0: that many leaves per round.
-extern "C" int azh_engine_set_eval_round(azh_engine *e, int leaves)
-{
-    if (!e)
-        return azh_fail(-1, "azh_engine_set_eval_round: null engine");
-    e->eval_round = leaves < 0 ? -1 : leaves;
-    return 0;
-}
-
-// Leaves in the list the last tree launch of the device loop (or the last azh_engine_select) handed to the evaluator.
-extern "C" int azh_engine_leaf_count(azh_engine *e, int32_t *out)
-{
-    if (!e || !out)
-        return azh_fail(-1, "azh_engine_leaf_count: null argument");
-    AZH_HIP(hipStreamSynchronize(e->stream));
-    AZH_HIP(hipMemcpy(out, e->P.leaf_count, 4, hipMemcpyDeviceToHost));
-    return 0;
-}
-
 // Order in which finished games are handed out.  0 (default): as they finish.  1: by game uid — a game waits until
 // every game with a smaller uid has been written or dropped.  Games that finish first are the SHORT ones, so a
 // consumer that stops reading after N lines (looper.py:51-64 kills the generator at --game-count lines) gets a
@@ -2096,8 +2000,6 @@ extern "C" int azh_engine_set_positions(azh_engine *e, const uint64_t *boards, c
     if (rc == hipSuccess) rc = hipMemcpy(d_b, boards, G * 16, hipMemcpyHostToDevice);
     if (rc == hipSuccess) rc = hipMemcpy(d_p, plies, G * 4, hipMemcpyHostToDevice);
     if (rc == hipSuccess) rc = hipMemsetAsync(e->P.adv_count, 0, sizeof(int), e->stream);
-    // leaves a whole-rounds leaf list left over belong to the games that are being replaced
-    if (rc == hipSuccess) rc = hipMemsetAsync(e->P.need_mask, 0, 2 * (size_t)e->P.mask_words * sizeof(u32), e->stream);
     if (rc == hipSuccess) {
         hipLaunchKernelGGL(k_init_positions, dim3(e->P.G), dim3(WAVE), 0, e->stream, e->P, (const ulonglong2 *)d_b, (const int *)d_p);
         rc = hipStreamSynchronize(e->stream);

@@ -1178,7 +1178,6 @@ struct azh_net {
     float *d_shift = nullptr, *d_fcw = nullptr;
     float fc_b = 0.0f;
     NetDtypeBuffers bufs[3];
-    int round_boards[3] = {0, 0, 0};  // azh_net_round_boards, per dtype (0 = not asked yet)
 };
 
 static int net_pack(azh_net *net, int dt)
@@ -1368,20 +1367,6 @@ extern "C" void azh_net_destroy(azh_net *net)
 }
 
 
-// azh_net_round_boards: while this points somewhere, the launch functions below do not launch — they store how many
-// boards one round of the kernel they would have launched evaluates (boards per workgroup x workgroups resident on a CU,
-// as the runtime's occupancy query sees them with the kernel's LDS image, x CUs of the current device).
-static thread_local int *t_round_query = nullptr;
-
-static int round_of(const void *kernel, int threads, int lds_bytes, int boards, int dev)
-{
-    int per_cu = 0, cus = 0;
-    AZH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)lds_bytes));
-    AZH_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    *t_round_query = per_cu * cus * boards;
-    return 0;
-}
-
 template <int DT, int NB, int WPS, bool STAMP = false, int FT = F>
 static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
 {
@@ -1396,8 +1381,6 @@ static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
                                     G::LDS_BYTES));
         attr_set[dev] = true;
     }
-    if (t_round_query)
-        return round_of((const void *)k_tower<DT, NB, WPS, STAMP, FT>, G::NTHR, G::LDS_BYTES, G::BOARDS, dev);
     const int grid = (max_n + G::BOARDS - 1) / G::BOARDS;
     if (grid <= 0)
         return 0;
@@ -1419,8 +1402,6 @@ template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &
                                     Geo2::LDS_BYTES));
         attr_set[dev] = true;
     }
-    if (t_round_query)
-        return round_of((const void *)k_tower2<DT, STAMP>, NTHREADS, Geo2::LDS_BYTES, Geo2::BOARDS, dev);
     const int grid = (max_n + Geo2::BOARDS - 1) / Geo2::BOARDS;
     if (grid <= 0)
         return 0;
@@ -1586,27 +1567,6 @@ static int net_launch(azh_net *net, int dtype, const unsigned long long *d_board
     default:
         return six ? launch_tower<AZH_DTYPE_F16, 6, 1>(a, max_n, stream) : launch_tower<AZH_DTYPE_F16, 3, 2>(a, max_n, stream);
     }
-}
-
-// Boards one round of the tower evaluates: what the kernel net_launch picks for this net and dtype holds on the chip at
-// once (1536 for the 128-filter 16-bit towers on 256 CUs: 3 boards x 2 workgroups per CU).  The device loop cuts its leaf
-// lists to whole rounds (azh_engine_set_eval_round).  Cached per net and dtype.
-int azh_net_round_boards(azh_net *net, int dtype)
-{
-    if (!net || dtype < 0 || dtype > 2)
-        return azh_fail(-1, "azh_net_round_boards: bad argument");
-    if (net->round_boards[dtype] > 0)
-        return net->round_boards[dtype];
-    int r = 0;
-    t_round_query = &r;
-    const int rc = net_launch(net, dtype, nullptr, nullptr, nullptr, 3, 0ull, nullptr, nullptr, 0, nullptr, 0);
-    t_round_query = nullptr;
-    if (rc)
-        return rc;
-    if (r <= 0)
-        return azh_fail(-4, "azh_net_round_boards: occupancy query gave %d", r);
-    net->round_boards[dtype] = r;
-    return r;
 }
 
 // device temporary owned by a host function: released when the function returns, error paths included

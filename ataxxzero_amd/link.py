@@ -78,7 +78,6 @@ SIGNATURES = {
     "azh_net_destroy": (None, [_vp]),
     "azh_net_forward": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
     "azh_net_forward_sym": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
-    "azh_net_round_boards": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_net_bench": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P(_f32)]),
     "azh_net_stamps": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "azh_engine_create": (ctypes.c_int, [_P(Config), _P(_vp)]),
@@ -106,8 +105,6 @@ SIGNATURES = {
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
     "azh_format_record_json": (ctypes.c_int, [_vp, ctypes.c_int64, _i32, _vp, ctypes.c_int64, _P(ctypes.c_int64)]),
     "azh_engine_set_emit_order": (ctypes.c_int, [_vp, ctypes.c_int]),
-    "azh_engine_set_eval_round": (ctypes.c_int, [_vp, ctypes.c_int]),
-    "azh_engine_leaf_count": (ctypes.c_int, [_vp, _P(_i32)]),
     "azh_engine_set_positions": (ctypes.c_int, [_vp, _vp, _vp]),
     "azh_engine_set_game_limit": (ctypes.c_int, [_vp, ctypes.c_int64]),
     # the reference's ABI, link.py:8-32
@@ -296,13 +293,6 @@ class Net:
         check(load().azh_net_bench(self.h, dtype, n, iters, ctypes.byref(ms)))
         return float(ms.value)
 
-    def round_boards(self, dtype=DTYPE_BF16):
-        """Boards one round of the tower's workgroups evaluates on this device (1536 for the 16-bit towers on 256 CUs)."""
-        r = load().azh_net_round_boards(self.h, dtype)
-        if r < 0:
-            check(r)
-        return int(r)
-
     def stamps(self, n, wgs=64):
         out = np.zeros((wgs, 4, 128), dtype=np.uint64)
         check(load().azh_net_stamps(self.h, n, wgs, _ptr(out)))
@@ -395,16 +385,6 @@ class Engine:
     def set_emit_order(self, by_uid):
         """True: finished games are handed out in uid order (unbiased prefixes); False: as they finish."""
         check(load().azh_engine_set_emit_order(self.h, 1 if by_uid else 0))
-
-    def set_eval_round(self, leaves):
-        """Leaf lists of the device loop are cut to whole tower rounds: < 0 the tower's own round (default), 0 off."""
-        check(load().azh_engine_set_eval_round(self.h, int(leaves)))
-
-    def last_leaf_count(self):
-        """Leaves in the list most recently handed to the evaluator."""
-        n = _i32(0)
-        check(load().azh_engine_leaf_count(self.h, ctypes.byref(n)))
-        return int(n.value)
 
     def set_game_limit(self, games):
         """Play uids 0 .. games - 1 only; slots past the limit go idle (call before the first iteration)."""

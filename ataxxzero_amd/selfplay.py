@@ -78,7 +78,7 @@ class SelfPlay:
     the idle CUs.  The halves are independent game shards (distinct Philox streams)."""
 
     def __init__(self, conv_weights, bn_params, games, visits, dtype="bf16", seed=DEFAULT_SEED,
-                 fen=START_FEN_SELFPLAY, streams=1, eval_round=-1, **cfg):
+                 fen=START_FEN_SELFPLAY, streams=1, **cfg):
         self.dtype = link.DTYPES[dtype]
         self.net = link.Net(conv_weights, bn_params, model.BN_EPSILON)
         if streams < 1 or games % streams:
@@ -87,10 +87,6 @@ class SelfPlay:
                         for i in range(streams)]
         self.engine = self.engines[0]
         self.games = games
-        # leaf lists cut to whole tower rounds (azh_engine_set_eval_round): -1 the tower's own round, 0 off
-        for e in self.engines:
-            e.set_eval_round(eval_round)
-        self.eval_round = self.net.round_boards(self.dtype) if eval_round < 0 else eval_round
 
     def run(self, iterations):
         # every engine enqueues its whole run on its own streams (the calls are asynchronous): the half-batches then

@@ -178,7 +178,7 @@ def spread(sp, args, seed):
     return {"mean_ply": float(plies[pick].mean()), "source": SNAPSHOT}
 
 
-def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=None, select_budget=None, eval_round=None):
+def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=None, select_budget=None):
     """Another operating point measured the same way as the headline and reported beside it (never as `value`):
     BASELINE.json's north-star point (>= 10k concurrent games on one GPU, 400 sims/move), the headline workload with the
     evaluation cache on (the generator CLI's default), or with the f16 tower."""
@@ -186,7 +186,7 @@ def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=No
     dtype = dtype or args.dtype
     budget = args.select_budget if select_budget is None else select_budget
     sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=dtype, seed=selfplay.DEFAULT_SEED + 77,
-                           select_budget=budget, flags=flags, eval_round=args.eval_round if eval_round is None else eval_round)
+                           select_budget=budget, flags=flags)
     try:
         spread(sp, args, selfplay.DEFAULT_SEED + 77)
         d, finished, dt, tm, _ = measure(sp, args, steps, warmup)
@@ -196,7 +196,6 @@ def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=No
         tree_ms = (tm["select_ms"] + tm["backup_ms"]) / it
         tree_gbs = tree_bytes(d) / float(iters) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         return {"games": games, "dtype": dtype, "eval_cache": bool(flags), "select_budget": budget,
-                "eval_round": sp.eval_round, "evals_per_launch": d["nn_evals"] / float(iters),
                 "node_evals_per_s": d["steps"] / dt, "nn_evals_per_s": d["nn_evals"] / dt,
                 "cache_hits_per_s": d.get("cache_hits", 0) / dt, "plies_per_s": d["plies"] / dt, "games_per_s": d["games"] / dt,
                 "ms_per_iteration": 1e3 * dt / iters, "steps": steps,
@@ -288,10 +287,6 @@ def main():
                     help="tree levels per select launch and game (azh_config.select_budget; 0 = unlimited): deeper "
                          "descents park and resume next iteration, so a launch does not last as long as the deepest "
                          "line of the batch; every game still plays exactly the same search")
-    ap.add_argument("--eval-round", type=int, default=-1,
-                    help="azh_engine_set_eval_round: leaf lists longer than one round of the tower's workgroups over the "
-                         "chip are cut to whole rounds, the leaves left over wait one iteration (-1: the tower's own "
-                         "round, 1536 boards on 256 CUs; 0: off); every game still plays exactly the same search")
     ap.add_argument("--eval-cache", action="store_true",
                     help="AZH_FLAG_EVAL_CACHE: positions a game's search has already evaluated are not sent to the net "
                          "again (engine.py's NNEvaluator.cache).  Off in the headline: the C++ generator evaluates every "
@@ -344,8 +339,7 @@ def main():
     conv, bn = model.random_init(args.blocks, 128, seed=1)
     sp = selfplay.SelfPlay(conv, bn, games=args.games, visits=args.visits, dtype=args.dtype,
                            seed=distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank), streams=args.streams,
-                           select_budget=args.select_budget, flags=link.FLAG_EVAL_CACHE if args.eval_cache else 0,
-                           eval_round=args.eval_round)
+                           select_budget=args.select_budget, flags=link.FLAG_EVAL_CACHE if args.eval_cache else 0)
     ages = spread(sp, args, distrib.shard_seed(selfplay.DEFAULT_SEED, group.rank))
     d, finished, dt, tm, finished_per_step = measure(sp, args, args.steps, args.warmup, group)
     steps_total, t_max, rate = distrib.aggregate(group, d["steps"], dt)
@@ -380,7 +374,6 @@ def main():
                                % args.iters_per_step,
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
                        "select_budget": args.select_budget, "eval_cache": bool(args.eval_cache),
-                       "eval_round": sp.eval_round,
                        "setup": ("slots loaded with steady-state positions built from one complete generation of real games of "
                                  "this workload (%s, mean ply %.0f), trees grown for %d untimed iterations, then the warm-up"
                                  % (ages["source"], ages["mean_ply"], args.phase_fill)) if ages else "cold start",
@@ -425,9 +418,6 @@ def main():
                                                     flags=link.FLAG_EVAL_CACHE, select_budget=64)
                 out["target_10k_games_with_eval_cache"] = target_leg(conv, bn, args, flags=link.FLAG_EVAL_CACHE,
                                                                      select_budget=64)
-            if args.eval_round != 0:
-                # the headline workload with every leaf evaluated in the iteration that found it (ragged last tower round)
-                out["without_whole_rounds"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2, eval_round=0)
             if args.dtype == "bf16":
                 # the f16 tower on the headline workload: closer to the f32 search than bf16 (profiles/
                 # round2_precision_in_the_loop.json: top-1 100 % / TV 0.02 % vs 98.4 % / 1.7 %); BASELINE names bf16

@@ -109,11 +109,6 @@ int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards,
 int azh_net_forward_sym(azh_net *net, int dtype, int n, const uint64_t *leaf_boards, uint64_t blockers,
                         float *logits_out, float *values_out);
 
-/* Boards the tower evaluates in one round: boards per workgroup x the workgroups of the kernel it runs for this net and
- * dtype that the device holds at once (occupancy query x CUs; 1536 for the 128-filter 16-bit towers on 256 CUs).  A
- * launch over a whole number of rounds keeps every CU busy to its end; see azh_engine_set_eval_round.  < 0 on error. */
-int azh_net_round_boards(azh_net *net, int dtype);
-
 /* Measurement hook: average HIP-event milliseconds per launch of the tower kernel over
  * n synthetic boards (iters launches on one stream, 3 untimed warm-up launches). */
 int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out);
@@ -277,18 +272,6 @@ long long azh_engine_implicit_fetches(const azh_engine *e);
  * *used = bytes the line has; -6 if `cap` is smaller (nothing written), -2 if the words are not a well-formed record.
  * with_ids: the arena's two extra keys (slot, uid). */
 int azh_format_record_json(const uint32_t *rec, int64_t words, int32_t with_ids, char *buf, int64_t cap, int64_t *used);
-/* Whole rounds for the tower in the device loop (azh_engine_run; one net, i.e. not the arena).  The evaluator of the
- * reference takes whatever its workers have queued (cpp/self_play_client.cpp:683-712: the batch is what is ready); here
- * the leaf list of an iteration is cut to a whole number of tower rounds (azh_net_round_boards) when it is longer than
- * one: the leaves left over wait one iteration — their games skip the next tree launch — and open the next list, so
- * nobody waits twice in a row.  Scheduling only: per game the order select -> evaluate -> backup -> play is untouched
- * and a game's record does not depend on it (an evaluator whose output does not depend on a board's place in the batch
- * gives the same games with and without; tests/test_gpu_engine.py).  leaves < 0: the tower's own round (default);
- * 0: off; > 0: that many leaves per round. */
-int azh_engine_set_eval_round(azh_engine *e, int leaves);
-/* Leaves in the list most recently handed to the evaluator (the last tree launch of azh_engine_run that wrote one, or
- * the last azh_engine_select); waits for the engine's stream. */
-int azh_engine_leaf_count(azh_engine *e, int32_t *out);
 /* Order in which azh_engine_drain_json hands games out: 0 (default) as they finish; 1 by game uid (slot g plays
  * uids g, g + games, g + 2 games, ...): a finished game is held back until every game with a smaller uid has been
  * handed out or dropped.  The reference's workers write games as they finish (Worker::thread_main :637-642) and

@@ -19,11 +19,7 @@ def make_pair(games, visits, max_plies=400, edges_per_node=96, seed=77, fen=orc.
     ocfg = orc.make_config(games, visits, seed=seed, fen_str=fen, max_plies=max_plies,
                            edges_per_node=edges_per_node, weight=weight, flags=flags, select_budget=select_budget)
     gcfg = link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_})
-    ge = link.Engine(gcfg)
-    # iteration-for-iteration comparisons: every leaf is evaluated in the iteration that found it (the device loop's
-    # whole-rounds leaf lists move evaluations between iterations, not between games: test_whole_round_leaf_lists_*)
-    ge.set_eval_round(0)
-    return orc.Engine(ocfg), ge
+    return orc.Engine(ocfg), link.Engine(gcfg)
 
 
 def compare_all(oe, ge, games):
@@ -200,45 +196,6 @@ def test_game_limit_plays_exactly_the_games_below_it_and_then_idles():
     assert want[:len(lines)] == lines
     with pytest.raises(link.AzhError):
         limited.set_game_limit(0)
-
-
-@pytest.mark.parametrize("games,round_leaves", [(600, 96), (2500, -1), (8300, 1536)])
-def test_whole_round_leaf_lists_play_the_same_games(games, round_leaves):
-    """azh_engine_set_eval_round: the device loop cuts an iteration's leaf list to whole tower rounds and lets the leaves
-    left over wait one iteration.  That moves evaluations between iterations, never between games: with the f32 tower
-    (bit-identical wherever a board sits in a launch) the games played under every uid are the same lines, byte for
-    byte, as with the rounds off; and the lists really are whole rounds."""
-    conv, bn = model.random_init(1, 128, seed=9)
-    net = link.Net(conv, bn)
-    R = net.round_boards(link.DTYPE_F32) if round_leaves < 0 else round_leaves
-    assert R > 0 and R % 3 == 0 and net.round_boards(link.DTYPE_BF16) % 3 == 0
-    N = games + games // 2
-    ocfg = orc.make_config(games, 6, seed=5, max_plies=40)
-    mk = lambda: link.Engine(link.Config(**{n: getattr(ocfg, n) for n, _ in orc.Config._fields_}))
-    rounds, plain = mk(), mk()
-    rounds.set_eval_round(round_leaves)
-    plain.set_eval_round(0)
-    out = []
-    for e in (rounds, plain):
-        e.set_emit_order(True)
-        e.set_game_limit(N)
-        lines, counts = [], []
-        for _ in range(400):
-            e.run(net, 25, link.DTYPE_F32)
-            lines += e.drain_json()
-            counts.append(e.last_leaf_count())
-            st = e.stats()
-            if st["games"] + st["dropped"] >= N:
-                break
-        assert st["games"] + st["dropped"] == N and len(lines) == st["games"]
-        out.append((lines, st, counts))
-    (l_r, st_r, c_r), (l_p, st_p, c_p) = out
-    assert l_r == l_p and len(l_r) > games
-    for k in ("steps", "nn_evals", "plies", "games", "dropped", "levels", "children", "new_moves"):
-        assert st_r[k] == st_p[k], (k, st_r[k], st_p[k])
-    # every list longer than a round was a whole number of rounds; without the rounds such lists are ragged
-    assert all(c % R == 0 for c in c_r if c > R) and any(c > R for c in c_r)
-    assert any(c > R and c % R != 0 for c in c_p)
 
 
 def test_game_limit_matches_oracle_in_lockstep():
