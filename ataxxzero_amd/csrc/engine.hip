@@ -1647,6 +1647,8 @@ extern "C" void azh_engine_destroy(azh_engine *e)
         return;
     if (e->stream)
         (void)hipStreamSynchronize(e->stream);
+    if (e->stream2)
+        (void)hipStreamSynchronize(e->stream2);  // (a re-root launch may still be running under an abandoned run)
     for (auto ev : e->events)
         (void)hipEventDestroy(ev);
     for (void *p : e->allocs)
