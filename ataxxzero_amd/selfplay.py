@@ -74,8 +74,10 @@ class SelfPlay:
     With `streams` = 2 the games are split into two half-batches, each with its own engine
     and HIP stream, sharing one set of packed weights — the reference's double buffer
     (cpp/self_play_client.cpp:593-600, two fill buffers of `buffer_entries` rows): while one
-    half runs its tree kernels or the tail of its tower launch, the other half's tower fills
-    the idle CUs.  The halves are independent game shards (distinct Philox streams)."""
+    half runs its tree kernels or the ramp or tail of its tower launch, the other half's tower fills
+    the idle CUs (+10 % at 4096 games, +24 % at 2048, nothing from 16384 on:
+    profiles/round4_half_batches_and_reserved_cus.txt; bench.py's and the generator's default).
+    The halves are independent game shards (distinct Philox streams, their own uids)."""
 
     def __init__(self, conv_weights, bn_params, games, visits, dtype="bf16", seed=DEFAULT_SEED,
                  fen=START_FEN_SELFPLAY, streams=1, **cfg):
@@ -122,10 +124,13 @@ class SelfPlay:
             e.set_emit_order(by_uid)
 
     def set_game_limit(self, games):
-        """`games` games in all, then the slots go idle (one engine only: uids are per engine)."""
-        if len(self.engines) != 1:
-            raise ValueError("a game limit needs --streams 1")
-        self.engine.set_game_limit(games)
+        """`games` games in all, then the slots go idle.  uids are per engine: half-batch i of K plays its own uids
+        0 .. ceil((games - i) / K) - 1, so the limits add up to `games` (and may be raised later, like the engine's)."""
+        k = len(self.engines)
+        if games < k:
+            raise ValueError("a game limit of %d needs at most %d half-batches" % (games, games))
+        for i, e in enumerate(self.engines):
+            e.set_game_limit((games + k - 1 - i) // k)
 
     def fetch(self):
         """sync + finished games off the device; `drain` then formats them on the host while the GPU does something else"""

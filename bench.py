@@ -38,8 +38,9 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # MI355X_MICR
 HBM_PEAK_GBS = 8000.0
 SCATTERED_PEAK_GBS = 5300.0   # dependent scattered 672-B reads, >= 8192 chains in flight, measured (profiles/round3_random_chase.txt)
 ITERS_PER_STEP = 250
+STREAMS_OF_PMC_SUMMARY = [2]   # main() sets it to --streams: the committed PMC summary of the same command is per launch
 TIMING_STRIDE = 8        # every 8th iteration is event-timed (an event is a barrier packet in the queue)
-PMC_SUMMARY = os.path.join("profiles", "round3_bench_pmc_k_tower.txt")
+PMC_SUMMARY = os.path.join("profiles", "round4_bench_two_half_batches_pmc_k_tower.txt")
 
 
 def tree_bytes(d, logit_bytes=4):
@@ -54,7 +55,7 @@ def measured_traffic():
     MI355X_MICROARCH.md §HBM prescribes for gfx950, + WRITE_SIZE), as summarised by tools/prof_bench.sh into
     profiles/.  PMC counters cannot be read from inside the process, so this is the committed measurement, or null."""
     import re
-    for rel in (PMC_SUMMARY, os.path.join("profiles", "round2_bench_pmc_k_tower.txt")):
+    for rel in ((PMC_SUMMARY,) if STREAMS_OF_PMC_SUMMARY[0] == 2 else (os.path.join("profiles", "round4_bench_pmc_k_tower.txt"),)):
         try:
             m = re.search(r"x2 corrected: ([0-9.e+]+) MB\), WRITE_SIZE [0-9.e+]+ KiB \(([0-9.e+]+) MB\)",
                           open(os.path.join(ROOT, rel)).read())
@@ -178,7 +179,7 @@ def spread(sp, args, seed):
     return {"mean_ply": float(plies[pick].mean()), "source": SNAPSHOT}
 
 
-def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=None, select_budget=None):
+def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=None, select_budget=None, streams=1):
     """Another operating point measured the same way as the headline and reported beside it (never as `value`):
     BASELINE.json's north-star point (>= 10k concurrent games on one GPU, 400 sims/move), the headline workload with the
     evaluation cache on (the generator CLI's default), or with the f16 tower."""
@@ -186,16 +187,19 @@ def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=No
     dtype = dtype or args.dtype
     budget = args.select_budget if select_budget is None else select_budget
     sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=dtype, seed=selfplay.DEFAULT_SEED + 77,
-                           select_budget=budget, flags=flags)
+                           select_budget=budget, flags=flags, streams=streams)
     try:
         spread(sp, args, selfplay.DEFAULT_SEED + 77)
         d, finished, dt, tm, _ = measure(sp, args, steps, warmup)
         it = max(tm["iterations"], 1)
         iters = steps * args.iters_per_step
-        tf = d["nn_evals"] / float(iters) * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] / it * 1e-3) / 1e12
+        # per launch (one engine's): with half-batches in flight two launches share the chip, see main()
+        tf = d["nn_evals"] / float(iters * streams) * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] / it * 1e-3) / 1e12
         tree_ms = (tm["select_ms"] + tm["backup_ms"]) / it
-        tree_gbs = tree_bytes(d) / float(iters) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+        tree_gbs = tree_bytes(d) / float(iters * streams) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         return {"games": games, "dtype": dtype, "eval_cache": bool(flags), "select_budget": budget,
+                "half_batches_in_flight": streams, "evals_per_launch": d["nn_evals"] / float(iters * streams),
+                "tower_tflops_over_the_region": d["nn_evals"] * model.flops_per_eval(args.blocks, 128) / dt / 1e12,
                 "node_evals_per_s": d["steps"] / dt, "nn_evals_per_s": d["nn_evals"] / dt,
                 "cache_hits_per_s": d.get("cache_hits", 0) / dt, "plies_per_s": d["plies"] / dt, "games_per_s": d["games"] / dt,
                 "ms_per_iteration": 1e3 * dt / iters, "steps": steps,
@@ -278,7 +282,11 @@ def main():
     ap.add_argument("--visits", type=int, default=400)
     ap.add_argument("--blocks", type=int, default=12)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--streams", type=int, default=1, help="half-batches in flight per GPU (the reference's double buffer)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="half-batches in flight per GPU: the games are split into this many engines, each with its own HIP "
+                         "streams, sharing one set of packed weights (the reference's double buffer, cpp/self_play_client.cpp:"
+                         "593-600: B of its 2B games are evaluated at a time).  2: one half's tower fills the ramp, the drain "
+                         "and the tree phase of the other's (+10 %% at 4096 games, profiles/round4_half_batches_and_reserved_cus.txt)")
     ap.add_argument("--phase-fill", type=int, default=1000,
                     help="untimed set-up: the slots are loaded with steady-state positions (profiles/"
                          "round2_steady_state_positions.npz) and the trees are grown for this many iterations at full "
@@ -356,8 +364,15 @@ def main():
         it = max(tm["iterations"], 1)                # sampled launches (per half-batch when streams > 1)
         launch_ms = tm["net_ms"] / it
         evals_per_launch = d["nn_evals"] / float(iters * args.streams)
-        achieved_tf = evals_per_launch * flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+        launch_tf = evals_per_launch * flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+        # With half-batches in flight two launches of the tower share the chip most of the time, so a launch's own duration
+        # prices about half a chip.  The kernel's rate is then taken over the chip: every FLOP of the kernel in the timed
+        # region / the region's wall time (rank 0's) — a LOWER bound of the rate while a tower runs (the region also holds
+        # the moments in which none does).  With one batch (--streams 1) it is the launch's own rate, as before.
+        region_tf = d["nn_evals"] * flops / dt / 1e12
+        achieved_tf = launch_tf if args.streams == 1 else region_tf
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        STREAMS_OF_PMC_SUMMARY[0] = args.streams
         traffic, traffic_src = measured_traffic()
         tree_ms = (tm["select_ms"] + tm["backup_ms"]) / it
         tree_gbs = tree_bytes(d) / float(iters * args.streams) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
@@ -367,9 +382,10 @@ def main():
             "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init .npy-layout weights, seed 1; "
                                                               "self-play from the reference start position)",
-            "config": {"workload": "%d concurrent self-play games per GPU, %d sims/move, %dx128 conv net, %s "
+            "config": {"workload": "%d concurrent self-play games per GPU%s, %d sims/move, %dx128 conv net, %s "
                                    "(per-GPU shard of BASELINE configs[2]; configs[1] at the metric's 400 sims)"
-                                   % (args.games, args.visits, args.blocks, args.dtype),
+                                   % (args.games, "" if args.streams == 1 else " in %d half-batches of %d, each with its own streams"
+                                      % (args.streams, args.games // args.streams), args.visits, args.blocks, args.dtype),
                        "step": "%d search iterations over the whole batch + one drain of the finished games"
                                % args.iters_per_step,
                        "games_per_gpu": args.games, "half_batches_in_flight": args.streams, "visits": args.visits,
@@ -389,6 +405,12 @@ def main():
             "mean_plies_per_finished_game": plies_total / games_total if games_total else None,
             "roofline": {"bound": "mfma", "kernel": "%s<%s>" % ("k_tower" if args.dtype == "f32" or os.environ.get("AZH_TOWER") == "1" else "k_tower2", args.dtype), "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved_is": ("one launch's own rate: FLOPs per launch / its average duration (HIP events)" if args.streams == 1 else
+                                         "the kernel's rate over the chip: all its FLOPs in the timed region / the region's wall time "
+                                         "(%d launches share the chip: per_launch is one of them)" % args.streams),
+                         "kernel_flops_in_region": d["nn_evals"] * flops, "region_s": dt,
+                         "per_launch": {"evals_per_launch": evals_per_launch, "avg_launch_ms": launch_ms, "achieved": launch_tf,
+                                        "frac": launch_tf / peak, "launches_sharing_the_chip": args.streams},
                          "avg_launch_ms": launch_ms, "evals_per_launch": evals_per_launch,
                          "launches_timed": it, "launches_in_region": iters * args.streams, "flops_per_eval": flops},
             "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup + move-due mark + select + leaf-list compaction, one launch, four games per "
@@ -402,6 +424,9 @@ def main():
                                                           "frac": tree_gbs / SCATTERED_PEAK_GBS,
                                                           "source": "profiles/round3_random_chase.txt"},
                               "tree_phase_ms_per_iteration": tree_ms,
+                              "tree_phase_is": ("tower end -> next tower start on the engine's stream" if args.streams == 1 else
+                                                "tower end -> next tower start of ONE half-batch: its tree launch waits for the slots the "
+                                                "other half's tower workgroups free, and runs under that tower (one_batch has the launch alone)"),
                               "bytes_per_step": tree_bytes(d) / float(max(d["steps"], 1)),
                               "levels_per_step": d["levels"] / float(max(d["steps"], 1)),
                               "children_per_step": d["children"] / float(max(d["steps"], 1))},
@@ -409,19 +434,23 @@ def main():
             "counters": d,
         }
         sp.close()
-        if group.world == 1 and not args.no_target_leg and args.streams == 1:
+        if group.world == 1 and not args.no_target_leg:
+            if args.streams != 1:
+                # the headline workload as ONE batch: the tower launch and the tree launch alone on the chip, i.e. the
+                # kernels' own rooflines (frac = FLOPs per launch / launch duration; tree bytes / tree phase)
+                out["one_batch"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2)
             out["target_10k_games"] = target_leg(conv, bn, args)
             if not args.eval_cache:
                 # the same workload with AZH_FLAG_EVAL_CACHE (the generator CLI's default): MCTS steps/s and games/s rise,
                 # net evaluations/s do not (the headline keeps the C++ generator's rule: every new node goes to the net)
                 out["with_eval_cache"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2,
-                                                    flags=link.FLAG_EVAL_CACHE, select_budget=64)
+                                                    flags=link.FLAG_EVAL_CACHE, select_budget=64, streams=args.streams)
                 out["target_10k_games_with_eval_cache"] = target_leg(conv, bn, args, flags=link.FLAG_EVAL_CACHE,
                                                                      select_budget=64)
             if args.dtype == "bf16":
                 # the f16 tower on the headline workload: closer to the f32 search than bf16 (profiles/
                 # round2_precision_in_the_loop.json: top-1 100 % / TV 0.02 % vs 98.4 % / 1.7 %); BASELINE names bf16
-                out["with_f16"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2, dtype="f16")
+                out["with_f16"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2, dtype="f16", streams=args.streams)
         if group.world == 1 and not args.no_target_leg:
             out["config1_random_play"] = config1_leg()
         if group.world == 1 and not args.no_gemm_ceiling:

@@ -353,7 +353,11 @@ def test_bench_contract_line():
     assert abs(d["games_per_s"] * d["ms_per_step"] * 30e-3 - d["games_finished_in_timed_region"]) < 1e-6
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert 0 < r["launches_timed"] <= r["launches_in_region"] == 300
+    halves = d["config"]["half_batches_in_flight"]
+    assert halves == 2 and 0 < r["launches_timed"] <= r["launches_in_region"] == 300 * halves
+    # two launches share the chip: the kernel's rate is taken over the region, one launch's own rate stands beside it
+    assert abs(r["achieved"] - r["kernel_flops_in_region"] / r["region_s"] / 1e12) < 1e-6 * r["achieved"]
+    assert r["per_launch"]["launches_sharing_the_chip"] == 2 and r["per_launch"]["avg_launch_ms"] == r["avg_launch_ms"]
     assert r["avg_launch_ms"] < d["ms_per_iteration"]
     assert r["vendor_gemm_on_this_box"]["value"] > 100   # the library's bf16 GEMM on this box, measured beside the tower
     c = d["cpu_baseline"]

@@ -20,7 +20,8 @@ python3 - "$OUT" "$ARGS" > $OUT/timed_region.txt <<'PY'
 import csv, glob, os, re, sys
 f = max(glob.glob(os.path.join(sys.argv[1], "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
 m = re.search(r"--steps (\d+)", sys.argv[2])
-n = (int(m.group(1)) if m else 40) * 250
+h = re.search(r"--streams (\d+)", sys.argv[2])
+n = (int(m.group(1)) if m else 40) * 250 * (int(h.group(1)) if h else 2)   # bench.py's default: two half-batches in flight
 for name in ("k_tower", "k_tree", "k_advance_list"):
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if name in r["Kernel_Name"]]
     d = d[-n:]
