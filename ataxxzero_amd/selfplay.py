@@ -83,9 +83,11 @@ class SelfPlay:
                  fen=START_FEN_SELFPLAY, streams=1, **cfg):
         self.dtype = link.DTYPES[dtype]
         self.net = link.Net(conv_weights, bn_params, model.BN_EPSILON)
-        if streams < 1 or games % streams:
-            raise ValueError("games (%d) must be a positive multiple of streams (%d)" % (games, streams))
-        self.engines = [link.Engine(make_config(games // streams, visits, seed=seed + 1000003 * i, fen=fen, **cfg))
+        if streams < 1 or games < streams:
+            raise ValueError("games (%d) must be at least the number of half-batches (%d)" % (games, streams))
+        # (an uneven split gives the first games % streams engines one game more)
+        sizes = [games // streams + (1 if i < games % streams else 0) for i in range(streams)]
+        self.engines = [link.Engine(make_config(sizes[i], visits, seed=seed + 1000003 * i, fen=fen, **cfg))
                         for i in range(streams)]
         self.engine = self.engines[0]
         self.games = games

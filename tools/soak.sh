@@ -1,6 +1,6 @@
 #!/bin/bash
 # Full-scale soak of the drop-in generator: 12x128 random-init net, 400 visits, default buffer
-# (4096 games, one batch in flight) for $1 seconds; prints rate lines and game stats.
+# (4096 games in two half-batches in flight, the generator's default; EXTRA="--streams 1" for one batch) for $1 seconds; prints rate lines and game stats.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 SECS=${1:-120}
