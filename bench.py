@@ -38,9 +38,10 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # MI355X_MICR
 HBM_PEAK_GBS = 8000.0
 SCATTERED_PEAK_GBS = 5300.0   # dependent scattered 672-B reads, >= 8192 chains in flight, measured (profiles/round3_random_chase.txt)
 ITERS_PER_STEP = 250
-STREAMS_OF_PMC_SUMMARY = [2]   # main() sets it to --streams: the committed PMC summary of the same command is per launch
 TIMING_STRIDE = 8        # every 8th iteration is event-timed (an event is a barrier packet in the queue)
-PMC_SUMMARY = os.path.join("profiles", "round4_bench_two_half_batches_pmc_k_tower.txt")
+# rocprofv3 PMC summaries of this very command (tools/prof_bench.sh), per launch of the tower: by half-batches in flight
+PMC_SUMMARY = {2: os.path.join("profiles", "round4_bench_two_half_batches_pmc_k_tower.txt"),
+               1: os.path.join("profiles", "round4_bench_pmc_k_tower.txt")}
 
 
 def tree_bytes(d, logit_bytes=4):
@@ -50,12 +51,14 @@ def tree_bytes(d, logit_bytes=4):
             834 * logit_bytes * d["nn_evals"])
 
 
-def measured_traffic():
+def measured_traffic(streams):
     """HBM bytes per tower launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE, doubled as
     MI355X_MICROARCH.md §HBM prescribes for gfx950, + WRITE_SIZE), as summarised by tools/prof_bench.sh into
     profiles/.  PMC counters cannot be read from inside the process, so this is the committed measurement, or null."""
     import re
-    for rel in ((PMC_SUMMARY,) if STREAMS_OF_PMC_SUMMARY[0] == 2 else (os.path.join("profiles", "round4_bench_pmc_k_tower.txt"),)):
+    for rel in (PMC_SUMMARY.get(streams),):
+        if rel is None:
+            break
         try:
             m = re.search(r"x2 corrected: ([0-9.e+]+) MB\), WRITE_SIZE [0-9.e+]+ KiB \(([0-9.e+]+) MB\)",
                           open(os.path.join(ROOT, rel)).read())
@@ -372,8 +375,7 @@ def main():
         region_tf = d["nn_evals"] * flops / dt / 1e12
         achieved_tf = launch_tf if args.streams == 1 else region_tf
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        STREAMS_OF_PMC_SUMMARY[0] = args.streams
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src = measured_traffic(args.streams)
         tree_ms = (tm["select_ms"] + tm["backup_ms"]) / it
         tree_gbs = tree_bytes(d) / float(iters * args.streams) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
         out = {
