@@ -446,7 +446,7 @@ def main():
                 # the same workload with AZH_FLAG_EVAL_CACHE (the generator CLI's default): MCTS steps/s and games/s rise,
                 # net evaluations/s do not (the headline keeps the C++ generator's rule: every new node goes to the net)
                 out["with_eval_cache"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2,
-                                                    flags=link.FLAG_EVAL_CACHE, select_budget=64, streams=args.streams)
+                                                    flags=link.FLAG_EVAL_CACHE, streams=args.streams)
                 out["target_10k_games_with_eval_cache"] = target_leg(conv, bn, args, flags=link.FLAG_EVAL_CACHE,
                                                                      select_budget=64)
             if args.dtype == "bf16":

@@ -152,6 +152,35 @@ def test_two_half_batches_match_two_independent_engines():
     sp.close()
 
 
+def test_game_limit_is_split_over_uneven_half_batches():
+    """SelfPlay.set_game_limit with several engines: batch i of K plays its own uids 0 .. ceil((N - i) / K) - 1, the limits
+    add up to N, raising N later wakes idle slots, and batches may be of uneven size (65 games in 3: 22 + 22 + 21)."""
+    conv, bn = model.random_init(1, 128, seed=9)
+    sp = selfplay.SelfPlay(conv, bn, games=65, visits=6, dtype="f32", seed=5, streams=3, max_plies=60)
+    assert [e.G for e in sp.engines] == [22, 22, 21]
+    sp.set_emit_order(True)
+    with pytest.raises(ValueError):
+        sp.set_game_limit(2)
+    lines = []
+    for n_total in (100, 130):
+        sp.set_game_limit(n_total)
+        for _ in range(400):
+            sp.run(50)
+            lines += sp.drain()
+            st = sp.stats()
+            if st["games"] + st["dropped"] >= n_total:
+                break
+        assert st["games"] + st["dropped"] == n_total and len(lines) == st["games"]
+        per_engine = [(n_total + 2 - i) // 3 for i in range(3)]
+        assert sum(per_engine) == n_total
+        for e, lim in zip(sp.engines, per_engine):
+            assert all(e.game_state(g).phase == 3 and e.game_state(g).uid >= lim for g in range(e.G))
+    sp.run(20)
+    sp.sync()
+    assert sp.stats() == st and sp.drain() == []
+    sp.close()
+
+
 def test_looper_iteration_generate_train_generate(tmp_path):
     """One iteration of looper.py's main loop (looper.py:117-153) with the two commands it issues:
     accelerated_generate_games.py on model-001, train.py -> model-002, generation again on model-002."""
