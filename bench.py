@@ -440,7 +440,14 @@ def main():
             if args.streams != 1:
                 # the headline workload as ONE batch: the tower launch and the tree launch alone on the chip, i.e. the
                 # kernels' own rooflines (frac = FLOPs per launch / launch duration; tree bytes / tree phase)
-                out["one_batch"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2)
+                ob = out["one_batch"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2)
+                alone = "the one_batch leg of this line: the same workload as one batch, every launch alone on the chip"
+                out["roofline"]["launch_alone_on_the_chip"] = {
+                    "evals_per_launch": ob["evals_per_launch"], "avg_launch_ms": ob["tower_ms_per_launch"],
+                    "achieved": ob["tower_tflops"], "frac": ob["tower_frac_of_peak"], "source": alone}
+                out["tree_roofline"]["launch_alone_on_the_chip"] = {
+                    "tree_phase_ms_per_iteration": ob["tree_ms_per_iteration"], "frac": ob["tree_roofline_frac"],
+                    "achieved": ob["tree_roofline_frac"] * HBM_PEAK_GBS, "source": alone}
             out["target_10k_games"] = target_leg(conv, bn, args)
             if not args.eval_cache:
                 # the same workload with AZH_FLAG_EVAL_CACHE (the generator CLI's default): MCTS steps/s and games/s rise,
