@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/gap_trace
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-leg --no-gemm-ceiling > $OUT/trace.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-target-leg --no-gemm-ceiling > $OUT/trace.log 2>&1 || exit 1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, os
 f = max(glob.glob(os.path.join(sys.argv[1], "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
