@@ -32,7 +32,10 @@ def random_openings(pairs, depth, seed):
         plies, results, trace, mv = link.random_play(2 * pairs + 16, (int(seed) << 8) + batch, x, o, bl, turn, max(depth + 1, 2))
         batch += 1
         for g in range(len(plies)):
-            if len(boards) < pairs and plies[g] > depth:        # still running after `depth` plies
+            # still running after `depth` plies, and no side had to pass on the way (a pass inside the opening would
+            # shift the mover's parity under the PGN replay; the reference's get_opening plays legal_moves(), which at
+            # these depths never holds a pass either)
+            if len(boards) < pairs and plies[g] > depth and not (mv[g, :depth] == 0xFFFF).any():
                 bx, bo = int(trace[g, depth, 0]) & ((1 << 63) - 1), int(trace[g, depth, 1])
                 boards.append([bx | ((depth & 1) << 63), bo])
                 moves.append([uai_move(int(m)) for m in mv[g, :depth]])
@@ -43,6 +46,8 @@ def uai_move(mv):
     """u16 (from | to << 8, square = file + 7 * rank) -> UAI text (uai_interface.py:11-22)"""
     def sq(s):
         return "abcdefg"[s % 7] + str(s // 7 + 1)
+    if mv == 0xFFFF:
+        return "0000"          # a pass (uai_interface.py:12-13); the playout kernel's marker
     frm, to = mv & 0xFF, mv >> 8
     return sq(to) if frm == to else sq(frm) + sq(to)
 
@@ -52,6 +57,8 @@ class Match:
                  max_plies=400, opening_depth=0):
         if games % 2:
             raise ValueError("the number of concurrent games must be even (each pairing is played both ways)")
+        if not 0 <= opening_depth < max_plies:
+            raise ValueError("opening_depth must be in 0 .. max_plies - 1 (%d), got %d" % (max_plies - 1, opening_depth))
         self.net_a = link.Net(*weights_a, model.BN_EPSILON)
         self.net_b = link.Net(*weights_b, model.BN_EPSILON)
         self.dtype = link.DTYPES[dtype]

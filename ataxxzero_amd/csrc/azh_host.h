@@ -35,3 +35,7 @@ int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, 
 int azh_net_launch_sym(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                        const int *d_count, int max_n, unsigned long long blockers, float *d_tmp_logits,
                        float *d_tmp_values, float *d_logits, float *d_values, hipStream_t stream);
+// two nets, two dense leaf lists, one launch (arena); 1 = not applicable here, nothing launched (launch them one by one)
+int azh_net_launch_pair(azh_net *net_a, azh_net *net_b, int dtype, const unsigned long long *d_boards, const int *d_list_a,
+                        const int *d_count_a, const int *d_list_b, const int *d_count_b, int max_n,
+                        unsigned long long blockers, float *d_logits, float *d_values, hipStream_t stream);

@@ -337,6 +337,34 @@ __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
 
 // ------------------------------------------------------------------ select + expand
 
+// Q + U of one edge (total_action_score :310-324) — IEEE division and square root in the fixed order the oracle restates.
+// -DAZH_FAST_SCORE=1 is a MEASUREMENT build only (never shipped, not bit-exact with the oracle): the two divisions and the
+// square root become single approximate instructions (v_rcp_f32 / v_sqrt_f32), i.e. the level's dependent chain without
+// the ~25 instructions that precomputing q = W/n and r = cP/(1+n) at backup time would remove — an upper bound of what
+// that restructuring could buy (profiles/round5_puct_chain_ab.txt).
+#ifndef AZH_FAST_SCORE
+#define AZH_FAST_SCORE 0
+#endif
+__device__ inline float puct_sqrt(float x)
+{
+#if AZH_FAST_SCORE
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+__device__ inline float puct_score(float prior, float W, u32 n, float sq, float c_puct)
+{
+#if AZH_FAST_SCORE
+    const float q = n ? W * __builtin_amdgcn_rcpf((float)n) : 0.0f;
+    const float u = (sq * __builtin_amdgcn_rcpf(1.0f + (float)n)) * (c_puct * prior);
+#else
+    const float q = n ? W / (float)n : 0.0f;
+    const float u = (sq / (1.0f + (float)n)) * (c_puct * prior);
+#endif
+    return u + q;
+}
+
 // `s` is the game's state, held in registers by the caller (the same values in all 64 lanes); written back here.
 // Returns what the leaf needs: 0 nothing, 1 an evaluation (by net A), 2 an evaluation by net B (arena).
 template <bool STAMP = false>
@@ -479,24 +507,16 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 }
                 const u32 n0 = edge_visits(e0), n1 = edge_visits(e1);
                 const u32 ntot1 = have_n ? n_node : wave_sum_u32(n0 + n1);
-                const float sq1 = sqrtf((float)(1u + ntot1));
+                const float sq1 = puct_sqrt((float)(1u + ntot1));
                 u32 bits0, bits1 = 0u;
                 bool valid0, valid1 = false;
                 {
-                    const float prior = u2f(e0.x);
-                    const float W = u2f(e0.y);
-                    const float q = n0 ? W / (float)n0 : 0.0f;
-                    const float u = (sq1 / (1.0f + (float)n0)) * (P.c_puct * prior);
-                    const float score = u + q;
+                    const float score = puct_score(u2f(e0.x), u2f(e0.y), n0, sq1, P.c_puct);
                     valid0 = live0 && score >= 0.0f;  // NaN scores are never selected by either reference
                     bits0 = valid0 ? f2u(score + 0.0f) : 0u;
                 }
                 if (two) {
-                    const float prior = u2f(e1.x);
-                    const float W = u2f(e1.y);
-                    const float q = n1 ? W / (float)n1 : 0.0f;
-                    const float u = (sq1 / (1.0f + (float)n1)) * (P.c_puct * prior);
-                    const float score = u + q;
+                    const float score = puct_score(u2f(e1.x), u2f(e1.y), n1, sq1, P.c_puct);
                     valid1 = live1 && score >= 0.0f;
                     bits1 = valid1 ? f2u(score + 0.0f) : 0u;
                 }
@@ -561,7 +581,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 }
             }
             const u32 ntot = have_n ? n_node : wave_sum_u32(nsum);
-            const float sq = sqrtf((float)(1u + ntot));
+            const float sq = puct_sqrt((float)(1u + ntot));
             // arg-max with ties to the LAST maximal edge (:354) — or the FIRST, python's max()
             // (engine.py:291), in the arena: scores are >= 0, so their bit patterns order like
             // the floats and (bits << 32 | index or ~index) is a total order; NaN scores (never
@@ -576,12 +596,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             for (int k = 0; k < 4; k++) {
                 const int j = lane + 64 * k;
                 if (k < rounds && j < M) {
-                    const float prior = u2f(ev[k].x);
-                    const u32 n = edge_visits(ev[k]);
-                    const float W = u2f(ev[k].y);
-                    const float q = n ? W / (float)n : 0.0f;
-                    const float u = (sq / (1.0f + (float)n)) * (P.c_puct * prior);
-                    const float score = u + q;
+                    const float score = puct_score(u2f(ev[k].x), u2f(ev[k].y), edge_visits(ev[k]), sq, P.c_puct);
                     const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)((u32)j ^ tie_flip) : 0ull;
                     if (kj > key) {
                         key = kj;
@@ -1510,6 +1525,9 @@ struct azh_engine {
     // that hands out no game) a drain with nothing staged returns empty instead of fetching — the caller has enqueued
     // its next run in between, and a fetch would wait for that run
     bool fetch_covers_drain = false;
+    // work has been enqueued since the last fetch (its finished games are still on the device): a drain by a caller that
+    // never fetches fetches when this is set — once per round, whether it drains in a loop until nothing comes or once
+    bool unfetched_work = true;
     long long implicit_fetches = 0;  // fetches made by azh_engine_drain_json itself (azh_engine_implicit_fetches)
     // uid-ordered emission: finished games wait here until every game with a smaller uid has been handed out or
     // is known to have been dropped ("" = dropped)
@@ -1683,6 +1701,7 @@ constexpr int ADV_GRID = 64;  // one wave each; a search iteration queues G * (1
 // signalled by the kernel's own completion (no separate event packet in the queue)
 static int enqueue_advance(azh_engine *e, hipStream_t stream, hipEvent_t done = nullptr)
 {
+    e->unfetched_work = true;  // (every path that can finish a game goes through here)
     hipExtLaunchKernelGGL(k_advance_list, dim3(ADV_GRID), dim3(WAVE), 0, stream, nullptr, done, 0, e->P);
     AZH_HIP(hipGetLastError());
     return 0;
@@ -1814,6 +1833,10 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
     if (iterations <= 0)
         return 0;
     const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
+    // arena: the two nets' towers as one launch (AZH_ARENA_PAIR=0: two launches back to back, for A/B runs)
+    const char *pair_s = getenv("AZH_ARENA_PAIR");  // (read per call: a test switches it inside one process)
+    const bool pair_env = !(pair_s && atoi(pair_s) == 0);
+    const bool pair = pair_env && two && !(e->P.flags & AZH_FLAG_SYMMETRY_AVG);
     // one fused tree launch; ev (or nullptr) is signalled by the kernel's own completion
     auto launch_tree = [&](bool stamped, int mode, hipEvent_t ev) {
         const bool small = e->P.G <= TREE_ONE_ROUND_GAMES;
@@ -1851,9 +1874,16 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
             e->close_pending = false;
         }
         if (rec) AZH_HIP(hipEventRecord(ev[0], e->stream));
-        int rc = launch_eval(e, net_a, dtype, e->P.leaf_list, e->P.leaf_count);
-        if (rc == 0 && net_b)
-            rc = launch_eval(e, net_b, dtype, e->P.leaf_list2, e->P.leaf_count2);
+        int rc = 1;
+        if (net_b && pair)  // both nets' leaf lists in ONE tower launch (1: not applicable -> one after the other)
+            rc = azh_net_launch_pair(net_a, net_b, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list,
+                                     e->P.leaf_count, e->P.leaf_list2, e->P.leaf_count2, e->P.G, e->P.blockers, e->P.logits,
+                                     e->P.values, e->stream);
+        if (rc == 1) {
+            rc = launch_eval(e, net_a, dtype, e->P.leaf_list, e->P.leaf_count);
+            if (rc == 0 && net_b)
+                rc = launch_eval(e, net_b, dtype, e->P.leaf_list2, e->P.leaf_count2);
+        }
         if (rc) return rc;
         if (rec) AZH_HIP(hipEventRecord(ev[1], e->stream));
         const int last = it + 1 == iterations;
@@ -2111,9 +2141,14 @@ extern "C" int azh_engine_timing(azh_engine *e, azh_timing *out)
 // the caller has enqueued in between (round 3's loop did exactly that and ran sequentially without saying so).
 static int fetch_records(azh_engine *e)
 {
+    // Everything on the engine's OWN streams: a fetch of one half-batch must not wait for the other half's run (the
+    // legacy null stream would: the engines' streams are blocking streams).
     AZH_HIP(hipStreamSynchronize(e->stream));
+    AZH_HIP(hipStreamSynchronize(e->stream2));  // (idle by now: the last tree launch of a run waits for the last re-roots)
+    e->unfetched_work = false;
     u64 head = 0;
-    AZH_HIP(hipMemcpy(&head, e->P.ring_head, 8, hipMemcpyDeviceToHost));
+    AZH_HIP(hipMemcpyAsync(&head, e->P.ring_head, 8, hipMemcpyDeviceToHost, e->stream));
+    AZH_HIP(hipStreamSynchronize(e->stream));
     if (head > e->P.ring_cap_words) {
         // A record or a drop marker did not fit (AZH_STAT_RING_OVERFLOW counts them): its uid will never come, and
         // uid order would wait for it for ever.  From here on the order is given up instead of the games: what is
@@ -2124,9 +2159,10 @@ static int fetch_records(azh_engine *e)
     if (head > 0) {
         const size_t at = e->staged.size();
         e->staged.resize(at + (size_t)head);
-        AZH_HIP(hipMemcpy(e->staged.data() + at, e->P.ring, (size_t)head * 4, hipMemcpyDeviceToHost));
-        AZH_HIP(hipMemset(e->P.ring, 0, (size_t)head * 4));
-        AZH_HIP(hipMemset(e->P.ring_head, 0, 8));
+        AZH_HIP(hipMemcpyAsync(e->staged.data() + at, e->P.ring, (size_t)head * 4, hipMemcpyDeviceToHost, e->stream));
+        AZH_HIP(hipMemsetAsync(e->P.ring, 0, (size_t)head * 4, e->stream));
+        AZH_HIP(hipMemsetAsync(e->P.ring_head, 0, 8, e->stream));
+        AZH_HIP(hipStreamSynchronize(e->stream));
     }
     return 0;
 }
@@ -2206,13 +2242,14 @@ extern "C" int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int6
     if (e->pending_pos >= e->pending.size()) {
         e->pending.clear();
         e->pending_pos = 0;
-        if (e->staged.empty() && !e->fetch_covers_drain) {
-            // a caller that never fetches: the drain does (and waits for whatever is enqueued)
+        if (e->staged.empty() && !e->fetch_covers_drain && e->unfetched_work) {
+            // a caller that never fetches: the drain does (and waits for whatever is enqueued) — once per round: the call
+            // that ends a drain loop finds no work enqueued since this fetch and returns empty without another one, and
+            // a caller that drains with ONE call per round gets a fetch in every round
             e->implicit_fetches++;
             const int rc = fetch_records(e);
             if (rc)
                 return rc;
-            e->fetch_covers_drain = true;  // one fetch per drain sequence: the call that ends it finds nothing new
         }
         if (!e->staged.empty())
             format_staged(e);

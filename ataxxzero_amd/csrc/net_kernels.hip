@@ -1000,21 +1000,17 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
     }
 }
 
+// The whole net for the workgroup's boards tile0 .. tile0 + 2 of the n (virtual) boards A lists.
 template <int DT, bool STAMP = false>
-__global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
+__device__ __forceinline__ void tower2_run(const TowerArgs &A, unsigned char *smem, int tile0, int n)
 {
     typedef Traits<DT> Tr;
     typedef Geo2 G;
     typedef typename Tr::afrag afrag;
-    extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is the same in all 64 lanes: say so, and everything derived from it (the weight stream's base
     // address above all) lives in scalar registers instead of being recomputed per lane
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
-    const int tile0 = blockIdx.x * G::BOARDS;
-    if (tile0 >= n)
-        return;
     const int nb = (n - tile0) < G::BOARDS ? (n - tile0) : G::BOARDS;
     unsigned long long *st = nullptr;
     if constexpr (STAMP) {
@@ -1095,6 +1091,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
         st[2] = stamp_now();
         st[104] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+template <int DT, bool STAMP = false>
+__global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
+    const int tile0 = blockIdx.x * Geo2::BOARDS;
+    if (tile0 >= n)
+        return;
+    tower2_run<DT, STAMP>(A, smem, tile0, n);
+}
+
+// Two nets in ONE launch (arena, uai_ringmaster.py:221-265: every position is searched by the net whose move it is): the
+// first ceil(nA / 3) workgroups evaluate list A with net A's weights, the following ceil(nB / 3) list B with net B's.
+// Everything that differs between the two — weights, shifts, value head, list, count, block count — is picked once per
+// workgroup from the kernel arguments with scalar selects (blockIdx is uniform); the body is the one k_tower2 runs, so a
+// board's result is bit for bit that of the single-net launch.  Two third-full launches back to back become one launch
+// whose workgroups all start together: at 2 x 500 leaves the iteration's evaluator time halves.
+template <int DT>
+__global__ __launch_bounds__(NTHREADS, 2) void k_tower2_pair(TowerArgs A, TowerArgs B)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int na = *A.count;
+    const int wga = (na + Geo2::BOARDS - 1) / Geo2::BOARDS;
+    const bool second = (int)blockIdx.x >= wga;
+    TowerArgs X = A;
+    if (second) {
+        X.conv_w2 = B.conv_w2;
+        X.head_w2 = B.head_w2;
+        X.shift = B.shift;
+        X.fc_w = B.fc_w;
+        X.fc_b = B.fc_b;
+        X.blocks = B.blocks;
+        X.list = B.list;
+    }
+    const int n = second ? *B.count : na;
+    const int tile0 = ((int)blockIdx.x - (second ? wga : 0)) * Geo2::BOARDS;
+    if (tile0 >= n)
+        return;
+    tower2_run<DT, false>(X, smem, tile0, n);
 }
 
 // ------------------------------------------------------------------ host side
@@ -1495,14 +1532,10 @@ int azh_net_launch_sym(azh_net *net, int dtype, const unsigned long long *d_boar
     return 0;
 }
 
-static int net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
-                      const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym)
+static TowerArgs tower_args(const azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
+                            const int *d_count, int max_n, unsigned long long blockers, float *d_logits, float *d_values,
+                            unsigned long long *d_stamps, int sym)
 {
-    if (dtype < 0 || dtype > 2)
-        return azh_fail(-2, "bad dtype %d", dtype);
-    if (net_pack(net, dtype))
-        return -1;
     TowerArgs a;
     a.conv_w = net->bufs[dtype].conv_w;
     a.head_w = net->bufs[dtype].head_w;
@@ -1521,6 +1554,57 @@ static int net_launch(azh_net *net, int dtype, const unsigned long long *d_board
     a.values = d_values;
     a.stamps = d_stamps;
     a.sym = sym;
+    return a;
+}
+
+// Two nets, two dense leaf lists, ONE launch (k_tower2_pair): the arena's evaluator.  Returns 1 — nothing launched — where
+// the fused pair kernel does not apply (f32, another width, AZH_TOWER=1, a device without the LDS range check): the caller
+// then launches the two nets one after the other.  max_n bounds count_a + count_b (a game has one leaf).
+int azh_net_launch_pair(azh_net *net_a, azh_net *net_b, int dtype, const unsigned long long *d_boards, const int *d_list_a,
+                        const int *d_count_a, const int *d_list_b, const int *d_count_b, int max_n,
+                        unsigned long long blockers, float *d_logits, float *d_values, hipStream_t stream)
+{
+    if (dtype != AZH_DTYPE_BF16 && dtype != AZH_DTYPE_F16)
+        return 1;
+    if (net_a->filters != 128 || net_b->filters != 128 || tower_variant() != 2 || !d_count_a || !d_count_b)
+        return 1;
+#if AZH_OOBZERO
+    if (lds_range_check() != 1)
+        return 1;
+#endif
+    if (net_pack(net_a, dtype) || net_pack(net_b, dtype))
+        return -1;
+    const TowerArgs a = tower_args(net_a, dtype, d_boards, d_list_a, d_count_a, max_n, blockers, d_logits, d_values, nullptr, 0);
+    const TowerArgs b = tower_args(net_b, dtype, d_boards, d_list_b, d_count_b, max_n, blockers, d_logits, d_values, nullptr, 0);
+    static bool attr_set[MAX_DEVICES][2] = {};
+    const int dev = current_device();
+    if (dev < 0)
+        return azh_fail(-4, "azh_net_launch_pair: hipGetDevice failed");
+    const int k = dtype == AZH_DTYPE_BF16 ? 0 : 1;
+    if (!attr_set[dev][k]) {
+        AZH_HIP(hipFuncSetAttribute(k == 0 ? (const void *)k_tower2_pair<AZH_DTYPE_BF16> : (const void *)k_tower2_pair<AZH_DTYPE_F16>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Geo2::LDS_BYTES));
+        attr_set[dev][k] = true;
+    }
+    // ceil(nA / 3) + ceil(nB / 3) <= (nA + nB) / 3 + 2 workgroups
+    const int grid = max_n / Geo2::BOARDS + 2;
+    if (k == 0)
+        hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b);
+    else
+        hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b);
+    AZH_HIP(hipGetLastError());
+    return 0;
+}
+
+static int net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
+                      const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
+                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym)
+{
+    if (dtype < 0 || dtype > 2)
+        return azh_fail(-2, "bad dtype %d", dtype);
+    if (net_pack(net, dtype))
+        return -1;
+    TowerArgs a = tower_args(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_logits, d_values, d_stamps, sym);
     if (sym)
         max_n *= 8;  // grid size: virtual boards
     if (net->filters != 128) {

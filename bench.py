@@ -40,8 +40,11 @@ SCATTERED_PEAK_GBS = 5300.0   # dependent scattered 672-B reads, >= 8192 chains 
 ITERS_PER_STEP = 250
 TIMING_STRIDE = 8        # every 8th iteration is event-timed (an event is a barrier packet in the queue)
 # rocprofv3 PMC summaries of this very command (tools/prof_bench.sh), per launch of the tower: by half-batches in flight
-PMC_SUMMARY = {2: os.path.join("profiles", "round4_bench_two_half_batches_pmc_k_tower.txt"),
-               1: os.path.join("profiles", "round4_bench_pmc_k_tower.txt")}
+PMC_SUMMARY = {2: os.path.join("profiles", "round5_bench_two_half_batches_pmc_k_tower.txt"),
+               1: os.path.join("profiles", "round5_bench_one_batch_pmc_k_tower.txt")}
+KERNEL_SOURCE = os.path.join("ataxxzero_amd", "csrc", "net_kernels.hip")
+SNAPSHOT_MEAN_GAME_PLIES = 152.42   # mean length of the 4096 games of the generation the steady-state snapshot was drawn from
+                                    # (profiles/round2_steady_state_positions.npz, meta.generation0_mean_plies; 400 sims/move)
 
 
 def tree_bytes(d, logit_bytes=4):
@@ -51,21 +54,33 @@ def tree_bytes(d, logit_bytes=4):
             834 * logit_bytes * d["nn_evals"])
 
 
+def source_sha256(rel=KERNEL_SOURCE):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def measured_traffic(streams):
     """HBM bytes per tower launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE, doubled as
     MI355X_MICROARCH.md §HBM prescribes for gfx950, + WRITE_SIZE), as summarised by tools/prof_bench.sh into
-    profiles/.  PMC counters cannot be read from inside the process, so this is the committed measurement, or null."""
+    profiles/.  PMC counters cannot be read from inside the process, so this is the committed measurement — and only while
+    it is a measurement of THIS kernel: the summary records the sha256 of the kernel source it was taken with, and a
+    summary of another source (or of none) gives null."""
     import re
-    for rel in (PMC_SUMMARY.get(streams),):
-        if rel is None:
-            break
-        try:
-            m = re.search(r"x2 corrected: ([0-9.e+]+) MB\), WRITE_SIZE [0-9.e+]+ KiB \(([0-9.e+]+) MB\)",
-                          open(os.path.join(ROOT, rel)).read())
-            return (float(m.group(1)) + float(m.group(2))) * 1e6, rel
-        except Exception:
-            continue
-    return None, None
+    rel = PMC_SUMMARY.get(streams)
+    if rel is None:
+        return None, None
+    try:
+        text = open(os.path.join(ROOT, rel)).read()
+        h = re.search(r"kernel source sha256: ([0-9a-f]{64})", text)
+        if not h or h.group(1) != source_sha256():
+            return None, "%s is not a measurement of the current %s (sha256 differs): stale, not reported" % (rel, KERNEL_SOURCE)
+        m = re.search(r"x2 corrected: ([0-9.e+]+) MB\), WRITE_SIZE [0-9.e+]+ KiB \(([0-9.e+]+) MB\)", text)
+        return (float(m.group(1)) + float(m.group(2))) * 1e6, rel
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(net, visits, dtype, seconds):
@@ -182,35 +197,94 @@ def spread(sp, args, seed):
     return {"mean_ply": float(plies[pick].mean()), "source": SNAPSHOT}
 
 
-def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=None, select_budget=None, streams=1):
+def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=None, select_budget=None, streams=1,
+               visits=None, blocks=None):
     """Another operating point measured the same way as the headline and reported beside it (never as `value`):
     BASELINE.json's north-star point (>= 10k concurrent games on one GPU, 400 sims/move), the headline workload with the
-    evaluation cache on (the generator CLI's default), or with the f16 tower."""
+    evaluation cache on (the generator CLI's default), with the f16 tower, or another BASELINE config.
+    In EVERY leg `tower_frac_of_peak` is the tower's rate over the chip — all its FLOPs in the leg's timed region / the
+    region's wall time, the definition of the headline's roofline.frac — and `per_launch_frac` is one launch's own rate
+    (FLOPs per launch / its average duration by HIP events: with two half-batches in flight it prices about half a chip)."""
     from ataxxzero_amd import model, selfplay
     dtype = dtype or args.dtype
+    visits = visits or args.visits
+    blocks = blocks or args.blocks
     budget = args.select_budget if select_budget is None else select_budget
-    sp = selfplay.SelfPlay(conv, bn, games=games, visits=args.visits, dtype=dtype, seed=selfplay.DEFAULT_SEED + 77,
+    sp = selfplay.SelfPlay(conv, bn, games=games, visits=visits, dtype=dtype, seed=selfplay.DEFAULT_SEED + 77,
                            select_budget=budget, flags=flags, streams=streams)
     try:
         spread(sp, args, selfplay.DEFAULT_SEED + 77)
         d, finished, dt, tm, _ = measure(sp, args, steps, warmup)
         it = max(tm["iterations"], 1)
         iters = steps * args.iters_per_step
-        # per launch (one engine's): with half-batches in flight two launches share the chip, see main()
-        tf = d["nn_evals"] / float(iters * streams) * model.flops_per_eval(args.blocks, 128) / (tm["net_ms"] / it * 1e-3) / 1e12
+        flops = model.flops_per_eval(blocks, 128)
+        launch_tf = d["nn_evals"] / float(iters * streams) * flops / (tm["net_ms"] / it * 1e-3) / 1e12
+        region_tf = d["nn_evals"] * flops / dt / 1e12
         tree_ms = (tm["select_ms"] + tm["backup_ms"]) / it
         tree_gbs = tree_bytes(d) / float(iters * streams) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
-        return {"games": games, "dtype": dtype, "eval_cache": bool(flags), "select_budget": budget,
-                "half_batches_in_flight": streams, "evals_per_launch": d["nn_evals"] / float(iters * streams),
-                "tower_tflops_over_the_region": d["nn_evals"] * model.flops_per_eval(args.blocks, 128) / dt / 1e12,
+        return {"games": games, "visits": visits, "net": "%dx128" % blocks, "dtype": dtype, "eval_cache": bool(flags),
+                "select_budget": budget, "half_batches_in_flight": streams,
                 "node_evals_per_s": d["steps"] / dt, "nn_evals_per_s": d["nn_evals"] / dt,
                 "cache_hits_per_s": d.get("cache_hits", 0) / dt, "plies_per_s": d["plies"] / dt, "games_per_s": d["games"] / dt,
                 "ms_per_iteration": 1e3 * dt / iters, "steps": steps,
-                "tower_ms_per_launch": tm["net_ms"] / it, "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[dtype],
+                "tower_tflops": region_tf, "tower_frac_of_peak": region_tf / MFMA_PEAK_TFLOPS[dtype],
+                "per_launch_tflops": launch_tf, "per_launch_frac": launch_tf / MFMA_PEAK_TFLOPS[dtype],
+                "evals_per_launch": d["nn_evals"] / float(iters * streams), "tower_ms_per_launch": tm["net_ms"] / it,
                 "tree_ms_per_iteration": tree_ms, "tree_roofline_frac": tree_gbs / HBM_PEAK_GBS,
                 "parked_share": d.get("parked", 0) / float(max(1, d.get("parked", 0) + d["steps"]))}
     finally:
         sp.close()
+
+
+def config5_leg(games=1000, visits=100, dtype="f16", seed=None):
+    """BASELINE configs[4] (uai_ringmaster.py with two uai_interface.py engines, :75-160,221-265) through this repo's batched
+    arena: a FIXED cohort of `games` games — every pairing both ways — between two random-init 12x128 nets (seeds 1 and 2),
+    `visits` MCTS steps per move from a fresh tree, played to completion as uai_ringmaster.py's drop-in plays it (25 search
+    iterations per round trip, finished games drained and scored).  The wall time is the longest game of the cohort at the
+    latency of a thinning batch; the rates are whole-cohort figures."""
+    from ataxxzero_amd import arena, model, selfplay
+    wa, wb = model.random_init(12, 128, seed=1), model.random_init(12, 128, seed=2)
+    m = arena.Match(wa, wb, visits, games=games, dtype=dtype, seed=selfplay.DEFAULT_SEED if seed is None else seed)
+    try:
+        m.run(5)            # first launches (weight packing, kernel load) outside the region
+        m.engine.sync()
+        st0 = m.engine.stats()
+        t0 = time.perf_counter()
+        done, wins, annulled, plies, rounds = 0, {"a": 0.0, "b": 0.0}, 0, 0, 0
+        while done < games:
+            m.run(25)
+            rounds += 1
+            for g in m.drain():
+                if g["uid"] >= games:
+                    continue   # a replacement game in a slot whose cohort game is over
+                done += 1
+                plies += len(g["moves"])
+                white = g["white"]
+                black = "b" if white == "a" else "a"
+                if g["result"] in (1, 2):
+                    wins[white if g["result"] == 1 else black] += 1
+                else:
+                    wins["a"] += 0.5
+                    wins["b"] += 0.5
+                    annulled += 1
+        m.engine.sync()
+        dt = time.perf_counter() - t0
+        st1 = m.engine.stats()
+        d = {k: st1[k] - st0[k] for k in st1}
+        flops = model.flops_per_eval(12, 128)
+        tf = d["nn_evals"] * flops / dt / 1e12
+        return {"workload": "uai_ringmaster.py: %d-game match (fixed cohort, every pairing both ways) of two random-init 12x128 "
+                            "nets (seeds 1, 2), %d visits/move, %s, all games in flight from the start" % (games, visits, dtype),
+                "games": done, "wall_s": dt, "games_per_s": done / dt, "mcts_steps_per_s": d["steps"] / dt,
+                "nn_evals_per_s": d["nn_evals"] / dt, "plies_per_s": d["plies"] / dt, "mean_plies": plies / float(max(done, 1)),
+                "search_iterations": 25 * rounds, "ms_per_iteration": 1e3 * dt / (25 * rounds),
+                "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[dtype],
+                "two_nets_in_one_launch": os.environ.get("AZH_ARENA_PAIR", "1") != "0",
+                "score": "%s - %s (annulled: %d)" % (wins["a"], wins["b"], annulled),
+                "reference": "uai_ringmaster.py:75-160,221-265 with two `uai_interface.py --visits %d` subprocesses "
+                             "(engine.py's Python MCTS, about 1.5 k steps/s by its author's constant; not runnable here: TensorFlow-1)" % visits}
+    finally:
+        m.close()
 
 
 def config1_leg(games=2000):
@@ -306,6 +380,14 @@ def main():
     ap.add_argument("--no-gemm-ceiling", action="store_true",
                     help="skip the vendor-library bf16 GEMM measured beside the roofline (context for roofline.frac)")
     ap.add_argument("--no-target-leg", action="store_true", help="skip the 16384-game leg reported beside the headline")
+    ap.add_argument("--legs", default="all",
+                    help="comma-separated legs to measure beside the headline (default all): one_batch, target_10k_games, "
+                         "with_eval_cache, target_10k_games_with_eval_cache, with_f16, config1_random_play, config2, config4, "
+                         "config5_arena")
+    ap.add_argument("--other-configs-games", type=int, default=0,
+                    help="games of the config2 / config4 / config5_arena legs (default: BASELINE's 4096 / 4096 / 1000)")
+    ap.add_argument("--arena-ab", action="store_true",
+                    help="also play the config5_arena leg with the two nets' towers as two launches back to back (AZH_ARENA_PAIR=0)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--plumbing-selftest", action="store_true",
                     help="NO GPU WORK: every rank reports fixed units so the launch / barrier / aggregation path of "
@@ -368,12 +450,13 @@ def main():
         launch_ms = tm["net_ms"] / it
         evals_per_launch = d["nn_evals"] / float(iters * args.streams)
         launch_tf = evals_per_launch * flops / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-        # With half-batches in flight two launches of the tower share the chip most of the time, so a launch's own duration
-        # prices about half a chip.  The kernel's rate is then taken over the chip: every FLOP of the kernel in the timed
-        # region / the region's wall time (rank 0's) — a LOWER bound of the rate while a tower runs (the region also holds
-        # the moments in which none does).  With one batch (--streams 1) it is the launch's own rate, as before.
+        # ONE definition whatever the number of half-batches: `achieved` is the kernel's rate over the chip — every FLOP of
+        # the kernel in the timed region / the region's wall time (rank 0's) — a LOWER bound of the rate while a tower runs
+        # (the region also holds the moments in which none does: tree phases with one batch, nothing much with two).  With
+        # half-batches in flight two launches share the chip most of the time and a launch's own duration prices about half
+        # a chip; one launch's own rate is reported as `per_launch` (and, every launch alone on the chip, by the one_batch leg).
         region_tf = d["nn_evals"] * flops / dt / 1e12
-        achieved_tf = launch_tf if args.streams == 1 else region_tf
+        achieved_tf = region_tf
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         traffic, traffic_src = measured_traffic(args.streams)
         tree_ms = (tm["select_ms"] + tm["backup_ms"]) / it
@@ -405,14 +488,18 @@ def main():
             "games_finished_in_timed_region": games_total,
             "games_finished_per_step_rank0": finished_per_step,   # flat = the loaded state is the steady state
             "mean_plies_per_finished_game": plies_total / games_total if games_total else None,
+            # the counted figure rests on a few hundred games finishing inside the region (+-5 %); every ply played in it is a
+            # 1 / (mean game length) share of a game: plies/s over the mean length of the generation the loaded state was drawn from
+            "games_per_s_from_plies": (plies_total / t_max / SNAPSHOT_MEAN_GAME_PLIES) if ages and args.visits == 400 else None,
+            "games_per_s_from_plies_is": "plies_per_s / %.2f plies per game (profiles/round2_steady_state_positions.npz, generation 0)" % SNAPSHOT_MEAN_GAME_PLIES,
             "roofline": {"bound": "mfma", "kernel": "%s<%s>" % ("k_tower" if args.dtype == "f32" or os.environ.get("AZH_TOWER") == "1" else "k_tower2", args.dtype), "achieved": achieved_tf, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "achieved_is": ("one launch's own rate: FLOPs per launch / its average duration (HIP events)" if args.streams == 1 else
-                                         "the kernel's rate over the chip: all its FLOPs in the timed region / the region's wall time "
-                                         "(%d launches share the chip: per_launch is one of them)" % args.streams),
+                         "achieved_is": "the kernel's rate over the chip: all its FLOPs in the timed region / the region's wall time "
+                                        "(%d launch(es) share the chip: per_launch is one of them; one_batch leg = a launch alone)" % args.streams,
                          "kernel_flops_in_region": d["nn_evals"] * flops, "region_s": dt,
                          "per_launch": {"evals_per_launch": evals_per_launch, "avg_launch_ms": launch_ms, "achieved": launch_tf,
                                         "frac": launch_tf / peak, "launches_sharing_the_chip": args.streams},
+                         "per_launch_frac": launch_tf / peak,
                          "avg_launch_ms": launch_ms, "evals_per_launch": evals_per_launch,
                          "launches_timed": it, "launches_in_region": iters * args.streams, "flops_per_eval": flops},
             "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup + move-due mark + select + leaf-list compaction, one launch, four games per "
@@ -436,32 +523,61 @@ def main():
             "counters": d,
         }
         sp.close()
-        if group.world == 1 and not args.no_target_leg:
-            if args.streams != 1:
-                # the headline workload as ONE batch: the tower launch and the tree launch alone on the chip, i.e. the
-                # kernels' own rooflines (frac = FLOPs per launch / launch duration; tree bytes / tree phase)
-                ob = out["one_batch"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2)
-                alone = "the one_batch leg of this line: the same workload as one batch, every launch alone on the chip"
-                out["roofline"]["launch_alone_on_the_chip"] = {
-                    "evals_per_launch": ob["evals_per_launch"], "avg_launch_ms": ob["tower_ms_per_launch"],
-                    "achieved": ob["tower_tflops"], "frac": ob["tower_frac_of_peak"], "source": alone}
-                out["tree_roofline"]["launch_alone_on_the_chip"] = {
-                    "tree_phase_ms_per_iteration": ob["tree_ms_per_iteration"], "frac": ob["tree_roofline_frac"],
-                    "achieved": ob["tree_roofline_frac"] * HBM_PEAK_GBS, "source": alone}
+        def want(leg):
+            return group.world == 1 and not args.no_target_leg and (args.legs == "all" or leg in args.legs.split(","))
+
+        if want("one_batch") and args.streams != 1:
+            # the headline workload as ONE batch: the tower launch and the tree launch alone on the chip, i.e. the
+            # kernels' own rooflines (frac = FLOPs per launch / launch duration; tree bytes / tree phase)
+            ob = out["one_batch"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2)
+            alone = "the one_batch leg of this line: the same workload as one batch, every launch alone on the chip"
+            out["roofline"]["launch_alone_on_the_chip"] = {
+                "evals_per_launch": ob["evals_per_launch"], "avg_launch_ms": ob["tower_ms_per_launch"],
+                "achieved": ob["per_launch_tflops"], "frac": ob["per_launch_frac"], "source": alone}
+            out["tree_roofline"]["launch_alone_on_the_chip"] = {
+                "tree_phase_ms_per_iteration": ob["tree_ms_per_iteration"], "frac": ob["tree_roofline_frac"],
+                "achieved": ob["tree_roofline_frac"] * HBM_PEAK_GBS, "source": alone}
+        if want("target_10k_games"):
             out["target_10k_games"] = target_leg(conv, bn, args)
-            if not args.eval_cache:
-                # the same workload with AZH_FLAG_EVAL_CACHE (the generator CLI's default): MCTS steps/s and games/s rise,
-                # net evaluations/s do not (the headline keeps the C++ generator's rule: every new node goes to the net)
+        if not args.eval_cache:
+            # the same workload with AZH_FLAG_EVAL_CACHE (the generator CLI's default): MCTS steps/s and games/s rise,
+            # net evaluations/s do not (the headline keeps the C++ generator's rule: every new node goes to the net)
+            if want("with_eval_cache"):
                 out["with_eval_cache"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2,
                                                     flags=link.FLAG_EVAL_CACHE, streams=args.streams)
+            if want("target_10k_games_with_eval_cache"):
                 out["target_10k_games_with_eval_cache"] = target_leg(conv, bn, args, flags=link.FLAG_EVAL_CACHE,
                                                                      select_budget=64)
-            if args.dtype == "bf16":
-                # the f16 tower on the headline workload: closer to the f32 search than bf16 (profiles/
-                # round2_precision_in_the_loop.json: top-1 100 % / TV 0.02 % vs 98.4 % / 1.7 %); BASELINE names bf16
-                out["with_f16"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2, dtype="f16", streams=args.streams)
-        if group.world == 1 and not args.no_target_leg:
+        if args.dtype == "bf16" and want("with_f16"):
+            # the f16 tower on the headline workload: closer to the f32 search than bf16 (profiles/
+            # round2_precision_in_the_loop.json: top-1 100 % / TV 0.02 % vs 98.4 % / 1.7 %); BASELINE names bf16
+            out["with_f16"] = target_leg(conv, bn, args, games=args.games, steps=6, warmup=2, dtype="f16", streams=args.streams)
+        if want("config1_random_play"):
             out["config1_random_play"] = config1_leg()
+        # BASELINE.json's other configs, measured like the headline (6 steps each) — beside the default headline, or when
+        # asked for by name (--legs)
+        default_headline = (args.visits, args.blocks, args.dtype, args.games) == (400, 12, "bf16", 4096)
+        og = args.other_configs_games
+        if want("config2") and (default_headline or args.legs != "all"):
+            # configs[1]: 4096 games, 200 sims/move, the 12x128 net, bf16
+            c2 = model.random_init(12, 128, seed=1)
+            out["config2"] = target_leg(c2[0], c2[1], args, games=og or 4096, steps=6, warmup=2, visits=200, blocks=12,
+                                        dtype="bf16", streams=args.streams)
+        if want("config4") and (default_headline or args.legs != "all"):
+            # configs[3]: 8 blocks x 128, fp16 MFMA, 800 sims/move (random-init seed 3)
+            c4 = model.random_init(8, 128, seed=3)
+            out["config4"] = target_leg(c4[0], c4[1], args, games=og or 4096, steps=6, warmup=2, visits=800, blocks=8,
+                                        dtype="f16", streams=args.streams)
+        if want("config5_arena") and (default_headline or args.legs != "all"):
+            # configs[4]: 1000-game arena of two nets
+            out["config5_arena"] = config5_leg(games=og or 1000)
+            if args.arena_ab:
+                # the same match with the two nets' towers launched one after the other (the round-4 loop), same box, same call
+                os.environ["AZH_ARENA_PAIR"] = "0"
+                try:
+                    out["config5_arena_two_launches"] = config5_leg(games=og or 1000)
+                finally:
+                    del os.environ["AZH_ARENA_PAIR"]
         if group.world == 1 and not args.no_gemm_ceiling:
             out["roofline"]["vendor_gemm_on_this_box"] = vendor_gemm_ceiling()
         if group.world == 1 and not args.no_cpu_baseline:

@@ -258,8 +258,11 @@ int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, 
  * A host loop that calls fetch, enqueues its next azh_engine_run and only then drains has the formatting and its own file
  * writes running under that run instead of in front of it (the reference's workers write their games from their own
  * threads, cpp/self_play_client.cpp:637-642: there, too, nobody waits for a game to be written).  Optional: a drain with
- * nothing fetched fetches by itself — except inside the drain sequence that follows an explicit fetch (the calls up to and
- * including the first one that returns *n_games == 0): those never touch the device, whatever was enqueued meanwhile. */
+ * nothing fetched fetches by itself whenever work has been enqueued since the last fetch (so a caller that never fetches gets
+ * one fetch per round, whether it drains in a loop until *n_games == 0 or with one call per round) — except inside the
+ * drain sequence that follows an explicit fetch (the calls up to and including the first one that returns *n_games == 0):
+ * those never touch the device, whatever was enqueued meanwhile.  A fetch touches only its own engine's streams: with
+ * several engines on one GPU (half-batches) fetching one does not wait for the others' runs. */
 int azh_engine_fetch(azh_engine *e);
 /* How many times azh_engine_drain_json had to fetch by itself (and so waited for the device) since the engine was created:
  * 0 for a host loop that fetches explicitly before every drain sequence. */

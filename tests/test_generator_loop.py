@@ -30,7 +30,8 @@ class FakeSelfPlay:
     """Every run "finishes" three games; they become visible to the host at the next fetch.  fetch / drain mirror the product:
     `drain` is link.Engine.drain_json (it calls the library's drain until a call hands out no game) and `_drain_call` is
     azh_engine_drain_json's state machine (csrc/engine.hip): a call with nothing pending and nothing staged fetches by
-    itself — and so waits for whatever run is enqueued — unless an explicit fetch covers the drain sequence."""
+    itself when work has been enqueued since the last fetch — and so waits for whatever run is enqueued — unless an
+    explicit fetch covers the drain sequence."""
 
     def __init__(self, conv, bn, games, visits, **kw):
         self.net = Net()
@@ -38,6 +39,7 @@ class FakeSelfPlay:
         self.in_flight = []      # games of the runs enqueued and not yet fetched
         self.staged = []         # fetched, not yet formatted
         self.covers = False      # an explicit fetch covers the drain sequence that follows it
+        self.unfetched_work = True   # a run has been enqueued since the last fetch
         self.old_semantics = bool(os.environ.get("FAKE_ROUND3_DRAIN"))   # round 3's library: every empty call fetched
         self.next_game = 0
         self.limit = None
@@ -56,6 +58,7 @@ class FakeSelfPlay:
 
     def run(self, iterations):
         calls.append(["run", iterations])
+        self.unfetched_work = True
         for _ in range(3):
             if self.limit is None or self.next_game < self.limit:
                 self.in_flight.append(self.next_game)
@@ -65,6 +68,7 @@ class FakeSelfPlay:
 
     def _fetch_records(self):
         time.sleep(0.01)         # the wait for the GPU: everything enqueued so far has to end
+        self.unfetched_work = False
         self.staged += self.in_flight
         self.counters["games"] += len(self.in_flight)
         self.in_flight = []
@@ -75,10 +79,9 @@ class FakeSelfPlay:
         self.covers = not self.old_semantics
 
     def _drain_call(self):
-        if not self.staged and not self.covers:
+        if not self.staged and not self.covers and (self.unfetched_work or self.old_semantics):
             calls.append(["fetch_in_drain"])
             self._fetch_records()
-            self.covers = not self.old_semantics   # one fetch per drain sequence
         out, self.staged = self.staged, []
         if not out:
             self.covers = False

@@ -94,6 +94,35 @@ def test_batched_two_net_match_bookkeeping():
             assert len(g["moves"]) == 300  # cut -> annulled
 
 
+@pytest.mark.parametrize("dtype,blocks_b", [("f16", 2), ("bf16", 3)])
+def test_two_nets_in_one_tower_launch_equal_two_launches(dtype, blocks_b, monkeypatch):
+    """The arena's evaluator (uai_ringmaster.py:221-265: each position goes to the net whose move it is): both nets' leaf
+    lists in ONE launch of the fused tower (k_tower2_pair; workgroups pick their weight set from the list they serve)
+    against the two launches back to back it replaces (AZH_ARENA_PAIR=0) — same games, same trees, every word: a board's
+    result does not depend on which launch carried it.  Nets of different depth included (blocks is per workgroup)."""
+    wa = model.random_init(2, 128, seed=21)
+    wb = model.random_init(blocks_b, 128, seed=22)
+    runs = []
+    for pair in ("1", "0"):
+        monkeypatch.setenv("AZH_ARENA_PAIR", pair)
+        m = arena.Match(wa, wb, visits=12, games=202, dtype=dtype, seed=9, max_plies=80)
+        lines = []
+        for _ in range(8):
+            m.run(120)
+            lines += m.engine.drain_json()
+        m.engine.sync()
+        states = [m.engine.game_state(g).as_tuple() for g in range(202)]
+        trees = [m.engine.tree(g) for g in range(0, 202, 7)]
+        runs.append((lines, states, trees, m.engine.stats()))
+        m.close()
+    (l1, s1, t1, st1), (l0, s0, t0, st0) = runs
+    assert st1 == st0 and st1["plies"] > 202 * 4 and st1["games"] + st1["dropped"] > 50
+    assert l1 == l0 and s1 == s0
+    for a, b in zip(t1, t0):
+        for x, y in zip(a, b):
+            assert (x == y).all()
+
+
 def test_match_from_random_openings(tmp_path):
     """uai_ringmaster.get_opening (uai_ringmaster.py:185-196, OPENING_DEPTH random plies, the same opening for both games of a
     pairing) as arena.Match(opening_depth=N) / `uai_ringmaster.py --opening-depth N`: the slots are loaded with the positions

@@ -104,10 +104,7 @@ def test_generate_games_random_play_cli(tmp_path):
     # beside BASELINE.md §2: the reference script, unmodified, one core of the build container: 74.5 s = 26.9 games/s
     note = ("config 1 (generate_games.py --random-play --game-count 2000): %s; whole process %.1f s = %.1f games/s; "
             "reference script 26.9 games/s" % (rate.split("] ", 1)[-1], wall, 2000 / wall))
-    print(note)
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "config1_rate.txt"), "w") as f:
-        f.write(note + "\n")
+    print(note)   # (the measurement proper is bench.py's config1_random_play leg; nothing is written outside tmp_path)
     plies = []
     for line in lines[:60]:
         assert '", "' not in line and "], [" in line  # json.dump default separators (generate_games.py:134)
@@ -387,10 +384,41 @@ def test_bench_contract_line():
     # two launches share the chip: the kernel's rate is taken over the region, one launch's own rate stands beside it
     assert abs(r["achieved"] - r["kernel_flops_in_region"] / r["region_s"] / 1e12) < 1e-6 * r["achieved"]
     assert r["per_launch"]["launches_sharing_the_chip"] == 2 and r["per_launch"]["avg_launch_ms"] == r["avg_launch_ms"]
-    assert r["avg_launch_ms"] < d["ms_per_iteration"]
+    assert r["avg_launch_ms"] < d["ms_per_iteration"] and abs(r["per_launch_frac"] - r["per_launch"]["frac"]) < 1e-12
+    assert r["traffic"] is None or r["traffic"] > 0   # null unless the committed PMC summary is of the current kernel source
     assert r["vendor_gemm_on_this_box"]["value"] > 100   # the library's bf16 GEMM on this box, measured beside the tower
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["null_evaluator_value"] > 0
+
+
+def test_bench_line_carries_every_baseline_config_with_one_definition_of_the_tower_fraction():
+    """BASELINE.json's configs[1], [3] and [4] are legs of the driver-run line (config2, config4, config5_arena; configs[0] =
+    config1_random_play, configs[2] = the headline's shard), and in every leg `tower_frac_of_peak` is the chip-wide figure
+    (all tower FLOPs of the leg's region / its wall time / peak) with `per_launch_frac` beside it.  Reduced game counts here;
+    the legs' own sims/move, nets and dtypes."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--games", "96", "--visits", "8", "--blocks", "1",
+                          "--steps", "4", "--warmup", "1", "--iters-per-step", "10", "--phase-fill", "20", "--no-cpu-baseline",
+                          "--no-gemm-ceiling", "--legs", "one_batch,with_f16,config2,config4,config5_arena",
+                          "--other-configs-games", "64", "--arena-ab"], cwd=ROOT, capture_output=True, timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    d = json.loads([l for l in res.stdout.decode().splitlines() if l.strip()][-1])
+    assert d["games_per_s_from_plies"] is None   # (only quoted for the 400-sim workload the snapshot was drawn from)
+    from ataxxzero_amd import model
+    for leg, visits, blocks, dtype in (("config2", 200, 12, "bf16"), ("config4", 800, 8, "f16")):
+        c = d[leg]
+        assert (c["visits"], c["net"], c["dtype"], c["games"], c["half_batches_in_flight"]) == (visits, "%dx128" % blocks, dtype, 64, 2)
+        assert c["node_evals_per_s"] > 0 and c["nn_evals_per_s"] > 0
+        tf = c["nn_evals_per_s"] * model.flops_per_eval(blocks, 128) / 1e12
+        assert abs(c["tower_tflops"] - tf) < 1e-6 * tf and abs(c["tower_frac_of_peak"] - tf / 2500.0) < 1e-9
+        assert c["per_launch_frac"] > 0 and abs(c["per_launch_frac"] - c["per_launch_tflops"] / 2500.0) < 1e-12
+    for leg in ("one_batch", "with_f16"):
+        assert "tower_frac_of_peak" in d[leg] and "per_launch_frac" in d[leg] and "tower_tflops_over_the_region" not in d[leg]
+    a, b = d["config5_arena"], d["config5_arena_two_launches"]
+    assert a["two_nets_in_one_launch"] is True and b["two_nets_in_one_launch"] is False
+    for c in (a, b):
+        assert c["games"] == 64 and c["wall_s"] > 0 and c["mcts_steps_per_s"] > 0 and c["tower_frac_of_peak"] > 0
+        assert abs(c["games_per_s"] * c["wall_s"] - 64) < 1e-6
+    assert a["score"] == b["score"] and a["mean_plies"] == b["mean_plies"]   # the same match, move for move
 
 
 def test_bench_py_two_ranks_on_one_gpu():
