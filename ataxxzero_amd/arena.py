@@ -76,8 +76,19 @@ class Match:
             boards, self.openings = random_openings(games // 2, opening_depth, seed)
             self.engine.set_positions(np.repeat(boards, 2, axis=0), np.full(games, opening_depth, dtype=np.int32))
 
+    def set_game_limit(self, games):
+        """The match is the games with uid < `games` (slot g plays uids g, g + concurrent, ...): a slot whose next game would be
+        past the limit goes idle instead of starting a game nobody scores, so the batch thins out as the match ends and its
+        last, longest games run at the latency of a nearly empty batch (azh_engine_set_game_limit)."""
+        self.engine.set_game_limit(games)
+
     def run(self, iterations):
         self.engine.run_arena(self.net_a, self.net_b, iterations, self.dtype)
+
+    def fetch(self):
+        """Waits for the iterations enqueued so far and takes their finished games off the device; a `run` enqueued between
+        this and `drain` executes while the host parses and scores them."""
+        self.engine.fetch()
 
     def drain(self):
         """Finished games: dicts with moves (UAI strings), result (1, 2 or 0 = cut), white ('a'/'b'),

@@ -76,10 +76,11 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_variant(name, extra_flags, force=False):
+def build_variant(name, extra_flags, force=False, replace=None):
     """A second copy of the library compiled with extra flags (e.g. ["-DAZH_OOBZERO=0"]), for A/B runs and for the test
     that keeps the tower's fallback build alive.  Load it with AZH_LIB=<path> in a fresh process.  Objects and library
-    live under csrc/_obj/variants/<name>/ (never shipped)."""
+    live under csrc/_obj/variants/<name>/ (never shipped).  `replace` = {"engine.hip": "/path/to/another/engine.hip"}
+    compiles a unit from another file (an earlier version of a kernel against the current one, same box, same call)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: a variant build needs the compiler")
@@ -89,11 +90,11 @@ def build_variant(name, extra_flags, force=False):
     deps = _deps()
     objs, procs = [], []
     for src, extra in UNITS:
-        s = os.path.join(CSRC, src)
+        s = (replace or {}).get(src) or os.path.join(CSRC, src)
         o = os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + deps):
-            procs.append((src, subprocess.Popen([hipcc] + COMMON + extra + list(extra_flags) + ["-c", s, "-o", o],
+            procs.append((src, subprocess.Popen([hipcc] + COMMON + extra + list(extra_flags) + ["-I" + CSRC, "-c", s, "-o", o],
                                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     failed = ["%s:\n%s" % (src, out.decode(errors="replace")) for src, p in procs
               for out in [p.communicate()[0]] if p.returncode != 0]

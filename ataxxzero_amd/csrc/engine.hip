@@ -345,6 +345,9 @@ __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
 #ifndef AZH_FAST_SCORE
 #define AZH_FAST_SCORE 0
 #endif
+#ifndef AZH_SQRT_EARLY
+#define AZH_SQRT_EARLY 1
+#endif
 __device__ inline float puct_sqrt(float x)
 {
 #if AZH_FAST_SCORE
@@ -413,6 +416,16 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
         // came through at hand and sums once.
         bool have_n = !resume;
         u32 n_node = (u32)s.root_visits;
+        // sqrt(1 + N) of the node about to be scanned, computed as soon as N is known — at the END of the level above, while
+        // the node's records are still on their way — instead of after their arrival: the IEEE square root (a dozen
+        // instructions) leaves the chain between the arrival of a level's records and the request for the next level's.
+        // Same function of the same argument: nothing the oracle could see.  (AZH_SQRT_EARLY=0: where it used to be.)
+        auto sqrt_1p = [](u32 n) {
+            float r = puct_sqrt((float)(1u + n));
+            asm volatile("" : "+v"(r));  // computed HERE (the optimiser would otherwise sink it to its use behind the wait)
+            return r;
+        };
+        float sq_node = sqrt_1p(n_node);
         // The path of the descent: lane k keeps the k-th entry added in this launch and the entries are stored together
         // afterwards (every 64 levels when there is no budget): a store per level would have to be acknowledged before
         // the next level's records count as arrived (vmcnt counts stores in order with the loads).
@@ -435,153 +448,181 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
         // already on the way: a level then costs max(memory latency, its instructions) instead of their sum.
         // (two records per lane: nodes of up to 128 moves take this path — a third of the nodes of a mid-game position have
         // more than 64)
-        uint4 ea0 = fresh_edge(0u), ea1 = fresh_edge(0u), en0 = fresh_edge(0u), en1 = fresh_edge(0u);
-        bool cur_loaded = false;
+        // Two sets of record registers take turns without a register-to-register copy: a level that scans set a requests
+        // the remembered child's records into set b; if the scores pick that child, the next level — a second copy of the
+        // level's code — scans set b and requests into set a.  Only set a is ever live across the loop's back edge.
+        uint4 ea0 = fresh_edge(0u), ea1 = fresh_edge(0u), eb0 = fresh_edge(0u), eb1 = fresh_edge(0u);
+        bool cur_loaded = false;  // the records of the node about to be scanned have been requested (set a at the loop's head)
+        // Every lane loads: lanes past the node's last edge read that last edge again (same cache line, no traffic) — no
+        // lane mask around the load, so no register has to be cleared or merged per request; every use below is masked by
+        // live0 / live1 or reads a lane the node's edge count has been checked against.  (cnt >= 1 at both call sites.)
         auto load_children = [&](u32 k, uint4 &r0, uint4 &r1) {
             const int cnt = kid_count(k);
-            const u32 f = kid_first(k);
-            r0 = fresh_edge(0u);
-            r1 = fresh_edge(0u);
-            if (lane < cnt)
-                r0 = A.ed[f + (u32)lane];
-            if (cnt > WAVE && lane + WAVE < cnt)
-                r1 = A.ed[f + (u32)(lane + WAVE)];
+            const u32 f = kid_first(k), last = (u32)cnt - 1u;
+            r0 = A.ed[f + min((u32)lane, last)];
+            if (cnt > WAVE)
+                r1 = A.ed[f + min((u32)(lane + WAVE), last)];
         };
-        for (;;) {
+        u32 sel_eidx = 0;
+        // One level of the fast path (all but a handful of nodes): one edge per lane, two beyond 64 moves.  Same arithmetic
+        // as the general path below; the arg-max is a 32-bit max of the score bits plus ballots for the tie rule, instead of
+        // a 64-bit (score, index) key reduction — this loop is a latency chain, instructions count.  Scans (c0, c1),
+        // requests into (p0, p1).  true: descended into a child; false: the chosen edge has no child (sel_eidx: expand it).
+        auto fast_level = [&](uint4 &c0, uint4 &c1, uint4 &p0, uint4 &p1, int M, u32 first) -> bool {
+            if (!cur_loaded)
+                load_children(kid, c0, c1);
+            cur_loaded = false;
+            const uint4 &e0 = c0, &e1 = c1;
+            const bool two = M > WAVE;
+            const bool live0 = lane < M, live1 = two && lane + WAVE < M;
+            // the remembered child, requested before anything is scored
+            const u64 unv0 = __ballot(live0 && edge_child(e0) == ENONE);
+            const u64 unv1 = two ? __ballot(live1 && edge_child(e1) == ENONE) : 0ull;
+            int u0 = -1, pv = -1, pred = -1;
+            if (unv0 | unv1) {
+                u32 hw;
+                if (unv0) {
+                    u0 = __ffsll((long long)unv0) - 1;
+                    hw = (u32)read_lane((int)e0.w, u0);
+                } else {
+                    u0 = __ffsll((long long)unv1) - 1;
+                    hw = (u32)read_lane((int)e1.w, u0);
+                    u0 += WAVE;
+                }
+                if ((hw >> 31) && (int)(hw & 0xFFu) < M) {
+                    pv = (int)(hw & 0xFFu);
+                    u32 pz, pk;
+                    if (pv < WAVE) {
+                        pz = (u32)read_lane((int)e0.z, pv);
+                        pk = (u32)read_lane((int)e0.w, pv);
+                    } else {
+                        pz = (u32)read_lane((int)e1.z, pv - WAVE);
+                        pk = (u32)read_lane((int)e1.w, pv - WAVE);
+                    }
+                    if ((pz >> 16) != ENONE && !kid_finished(pk) && kid_count(pk) > 0 && kid_count(pk) <= 2 * WAVE) {
+                        load_children(pk, p0, p1);
+                        pred = pv;
+                    }
+                }
+            }
+            const u32 n0 = edge_visits(e0), n1 = edge_visits(e1);
+            float sq1;
+            if (AZH_SQRT_EARLY && have_n)
+                sq1 = sq_node;
+            else
+                sq1 = puct_sqrt((float)(1u + (have_n ? n_node : wave_sum_u32((live0 ? n0 : 0u) + (live1 ? n1 : 0u)))));
+            u32 bits0, bits1 = 0u;
+            bool valid0, valid1 = false;
+            {
+                const float score = puct_score(u2f(e0.x), u2f(e0.y), n0, sq1, P.c_puct);
+                valid0 = live0 && score >= 0.0f;  // NaN scores are never selected by either reference
+                bits0 = valid0 ? f2u(score + 0.0f) : 0u;
+            }
+            if (two) {
+                const float score = puct_score(u2f(e1.x), u2f(e1.y), n1, sq1, P.c_puct);
+                valid1 = live1 && score >= 0.0f;
+                bits1 = valid1 ? f2u(score + 0.0f) : 0u;
+            }
+            const u32 top = wave_max_u32(bits0 > bits1 ? bits0 : bits1);
+            const u64 cand0 = __ballot(valid0 && bits0 == top);
+            const u64 cand1 = two ? __ballot(valid1 && bits1 == top) : 0ull;
+            int bj = 0;
+            if (P.flags & AZH_FLAG_TIE_FIRST) {
+                if (cand0)
+                    bj = __ffsll((long long)cand0) - 1;
+                else if (cand1)
+                    bj = WAVE + __ffsll((long long)cand1) - 1;
+            } else {
+                if (cand1)
+                    bj = WAVE + 63 - __clzll((long long)cand1);
+                else if (cand0)
+                    bj = 63 - __clzll((long long)cand0);
+            }
+            const u32 eidx = first + (u32)bj;
+            push_path(eidx);
+            // the chosen edge: visits | child << 16, and the child's range
+            u32 zsel, wsel;
+            if (bj < WAVE) {
+                zsel = (u32)read_lane((int)e0.z, bj);
+                wsel = (u32)read_lane((int)e0.w, bj);
+            } else {
+                zsel = (u32)read_lane((int)e1.z, bj - WAVE);
+                wsel = (u32)read_lane((int)e1.w, bj - WAVE);
+            }
+            const u32 child = zsel >> 16;
+            if (child == ENONE) {
+                sel_eidx = eidx;
+                return false;
+            }
+            // remember the choice (stored only when it changes)
+            if (u0 >= 0 && bj != pv && lane == 0)
+                reinterpret_cast<u32 *>(&A.ed[first + (u32)u0])[3] = 0x80000000u | (u32)bj;
+            node = child;
+            kid = wsel;
+            n_node = (zsel & 0xFFFFu) - 1u;
+            have_n = true;
+            if (AZH_SQRT_EARLY)
+                sq_node = sqrt_1p(n_node);  // (while the requested records are on their way)
+            if (pred == bj)
+                cur_loaded = true;  // the records requested before the scores were computed are the next level's
+            return true;
+        };
+        // what every level starts with: the level budget, finished positions, the counters.  true: the descent ends here.
+        int M = 0;
+        u32 first = 0;
+        auto level_begin = [&]() -> bool {
             if (P.select_budget != 0 && levels_done == P.select_budget) {
                 kind = AZH_LEAF_DESCENT;  // park: no leaf for the evaluator from this game this iteration
                 leaf_node = (int)node;
                 st_parked = 1;
-                break;
+                return true;
             }
             levels_done++;
-            const int M = kid_count(kid);
-            const u32 first = kid_first(kid);
+            M = kid_count(kid);
+            first = kid_first(kid);
             if (kid_finished(kid) || M == 0) {
                 kind = AZH_LEAF_TERMINAL;  // select_action -> NO_MOVE (:336-340)
                 leaf_node = (int)node;
-                break;
+                return true;
             }
             st_levels += 1;
             st_children += (u64)M;
-            u32 sel_eidx = 0;
+            return false;
+        };
+        bool expand = false;
+        for (;;) {
+            if (level_begin())
+                break;
             if (M <= 2 * WAVE) {
-                // Fast path (all but a handful of nodes): one edge per lane, two beyond 64 moves.  Same arithmetic as the
-                // general path below; the arg-max is a 32-bit max of the score bits plus ballots for the tie rule,
-                // instead of a 64-bit (score, index) key reduction — this loop is a latency chain, instructions count.
+                if (!fast_level(ea0, ea1, eb0, eb1, M, first)) {
+                    expand = true;
+                    break;
+                }
                 if (!cur_loaded)
-                    load_children(kid, ea0, ea1);
-                cur_loaded = false;
-                const uint4 e0 = ea0, e1 = ea1;
-                const bool two = M > WAVE;
-                const bool live0 = lane < M, live1 = two && lane + WAVE < M;
-                // the remembered child, requested before anything is scored
-                const u64 unv0 = __ballot(live0 && edge_child(e0) == ENONE);
-                const u64 unv1 = two ? __ballot(live1 && edge_child(e1) == ENONE) : 0ull;
-                int u0 = -1, pv = -1, pred = -1;
-                if (unv0 | unv1) {
-                    u32 hw;
-                    if (unv0) {
-                        u0 = __ffsll((long long)unv0) - 1;
-                        hw = (u32)read_lane((int)e0.w, u0);
-                    } else {
-                        u0 = __ffsll((long long)unv1) - 1;
-                        hw = (u32)read_lane((int)e1.w, u0);
-                        u0 += WAVE;
-                    }
-                    if ((hw >> 31) && (int)(hw & 0xFFu) < M) {
-                        pv = (int)(hw & 0xFFu);
-                        u32 pz, pk;
-                        if (pv < WAVE) {
-                            pz = (u32)read_lane((int)e0.z, pv);
-                            pk = (u32)read_lane((int)e0.w, pv);
-                        } else {
-                            pz = (u32)read_lane((int)e1.z, pv - WAVE);
-                            pk = (u32)read_lane((int)e1.w, pv - WAVE);
-                        }
-                        if ((pz >> 16) != ENONE && !kid_finished(pk) && kid_count(pk) > 0 && kid_count(pk) <= 2 * WAVE) {
-                            load_children(pk, en0, en1);
-                            pred = pv;
-                        }
-                    }
+                    continue;  // (the next level requests its records itself, into set a)
+                // the remembered child was chosen: its records are on their way into set b (it has 1 .. 128 moves)
+                if (level_begin())
+                    break;
+                if (!fast_level(eb0, eb1, ea0, ea1, M, first)) {
+                    expand = true;
+                    break;
                 }
-                const u32 n0 = edge_visits(e0), n1 = edge_visits(e1);
-                const u32 ntot1 = have_n ? n_node : wave_sum_u32(n0 + n1);
-                const float sq1 = puct_sqrt((float)(1u + ntot1));
-                u32 bits0, bits1 = 0u;
-                bool valid0, valid1 = false;
-                {
-                    const float score = puct_score(u2f(e0.x), u2f(e0.y), n0, sq1, P.c_puct);
-                    valid0 = live0 && score >= 0.0f;  // NaN scores are never selected by either reference
-                    bits0 = valid0 ? f2u(score + 0.0f) : 0u;
-                }
-                if (two) {
-                    const float score = puct_score(u2f(e1.x), u2f(e1.y), n1, sq1, P.c_puct);
-                    valid1 = live1 && score >= 0.0f;
-                    bits1 = valid1 ? f2u(score + 0.0f) : 0u;
-                }
-                const u32 top = wave_max_u32(bits0 > bits1 ? bits0 : bits1);
-                const u64 cand0 = __ballot(valid0 && bits0 == top);
-                const u64 cand1 = two ? __ballot(valid1 && bits1 == top) : 0ull;
-                int bj = 0;
-                if (P.flags & AZH_FLAG_TIE_FIRST) {
-                    if (cand0)
-                        bj = __ffsll((long long)cand0) - 1;
-                    else if (cand1)
-                        bj = WAVE + __ffsll((long long)cand1) - 1;
-                } else {
-                    if (cand1)
-                        bj = WAVE + 63 - __clzll((long long)cand1);
-                    else if (cand0)
-                        bj = 63 - __clzll((long long)cand0);
-                }
-                const u32 eidx = first + (u32)bj;
-                push_path(eidx);
-                // the chosen edge: visits | child << 16, and the child's range
-                u32 zsel, wsel;
-                if (bj < WAVE) {
-                    zsel = (u32)read_lane((int)e0.z, bj);
-                    wsel = (u32)read_lane((int)e0.w, bj);
-                } else {
-                    zsel = (u32)read_lane((int)e1.z, bj - WAVE);
-                    wsel = (u32)read_lane((int)e1.w, bj - WAVE);
-                }
-                const u32 child = zsel >> 16;
-                if (child != ENONE) {
-                    // remember the choice (stored only when it changes)
-                    if (u0 >= 0 && bj != pv && lane == 0)
-                        reinterpret_cast<u32 *>(&A.ed[first + (u32)u0])[3] = 0x80000000u | (u32)bj;
-                    if (pred == bj) {
-                        // (a real branch, not a select: a select would wait for the requested records — and for the store
-                        // above — on the path that does not use them)
-                        asm volatile("; the records requested before the scores were computed" ::);
-                        ea0 = en0;
-                        ea1 = en1;
-                        cur_loaded = true;
-                    }
-                    node = child;
-                    kid = wsel;
-                    n_node = (zsel & 0xFFFFu) - 1u;
-                    have_n = true;
-                    continue;
-                }
-                // fall through to the expansion below with the general path's variable
-                sel_eidx = eidx;
+                continue;  // (cur_loaded: set a holds the next level's records)
             } else {
             const int rounds = (M + 63) >> 6;
-            uint4 ev[4];
+            uint4 *const evp[4] = {&ea0, &ea1, &eb0, &eb1};  // the fast path's record registers (whatever they held is dead:
+#define ev(k) (*evp[k])                                        // cur_loaded is cleared below)
             u32 nsum = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                ev[k] = fresh_edge(0u);
                 const int j = lane + 64 * k;
                 if (k < rounds && j < M) {
-                    ev[k] = A.ed[first + j];
-                    nsum += edge_visits(ev[k]);
+                    ev(k) = A.ed[first + j];
+                    nsum += edge_visits(ev(k));
                 }
             }
             const u32 ntot = have_n ? n_node : wave_sum_u32(nsum);
-            const float sq = puct_sqrt((float)(1u + ntot));
+            const float sq = (AZH_SQRT_EARLY && have_n) ? sq_node : puct_sqrt((float)(1u + ntot));
             // arg-max with ties to the LAST maximal edge (:354) — or the FIRST, python's max()
             // (engine.py:291), in the arena: scores are >= 0, so their bit patterns order like
             // the floats and (bits << 32 | index or ~index) is a total order; NaN scores (never
@@ -591,20 +632,21 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             // no array is indexed by the (run-time) round of the winner (that put the arrays in scratch memory
             // and a scratch round trip into every level)
             u64 key = 0;
-            u32 mine = ev[0].z, mkid = ev[0].w;
+            u32 mine = ev(0).z, mkid = ev(0).w;  // (lane 0 always holds edge 0: the key-0 default below)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int j = lane + 64 * k;
                 if (k < rounds && j < M) {
-                    const float score = puct_score(u2f(ev[k].x), u2f(ev[k].y), edge_visits(ev[k]), sq, P.c_puct);
+                    const float score = puct_score(u2f(ev(k).x), u2f(ev(k).y), edge_visits(ev(k)), sq, P.c_puct);
                     const u64 kj = score >= 0.0f ? (((u64)f2u(score + 0.0f)) << 32) | (u64)((u32)j ^ tie_flip) : 0ull;
                     if (kj > key) {
                         key = kj;
-                        mine = ev[k].z;
-                        mkid = ev[k].w;
+                        mine = ev(k).z;
+                        mkid = ev(k).w;
                     }
                 }
             }
+#undef ev
             key = wave_max_u64(key);
             const int bj = key ? (int)((u32)key ^ tie_flip) : 0;  // key 0: edge 0 = lane 0's round-0 default
             const u32 eidx = first + (u32)bj;
@@ -616,11 +658,17 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 kid = (u32)read_lane((int)mkid, bj & 63);
                 n_node = (zsel & 0xFFFFu) - 1u;
                 have_n = true;
+                if (AZH_SQRT_EARLY)
+                    sq_node = sqrt_1p(n_node);
                 cur_loaded = false;
                 continue;
             }
             sel_eidx = eidx;
+            expand = true;
+            break;
             }
+        }
+        if (expand) {
             // expand (:429-439)
             if constexpr (STAMP) st[4] = tree_stamp();
             const u32 eidx = sel_eidx;
@@ -635,8 +683,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 kind = AZH_LEAF_NONE;
                 leaf_node = 0;
                 depth = 0;
-                break;
-            }
+            } else {
             const u32 cid = (u32)s.n_nodes;
             s.n_nodes += 1;
             u32 known = NONE;  // a node of this tree that already carries the evaluation of this position
@@ -685,7 +732,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             leaf_node = (int)cid;
             leaf_mover = cb.turn ? cb.o : cb.x;
             leaf_opp = cb.turn ? cb.x : cb.o;
-            break;
+            }
         }
         // the path entries of this launch, one store for all of them (none after an overflow: depth is 0 then)
         if (lane < depth - path_base)
@@ -1382,7 +1429,7 @@ __device__ inline void compact_leaves(const EngineParams &P, int two, int *s_cnt
 // its own: wave_sync, never a workgroup barrier, inside a game), and the last workgroup to finish compacts the leaf
 // list.  mode bit 0: backup + mark, bit 1: select (+ compaction).
 template <bool STAMP, int TREE_WAVES>
-__global__ __launch_bounds__(TREE_WAVES * WAVE) void k_tree(EngineParams P, int mode, int two)
+__global__ __launch_bounds__(TREE_WAVES * WAVE) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_tree(EngineParams P, int mode, int two)
 {
     __shared__ u16 s_moves[TREE_WAVES][MAX_MOVES];  // per game: the move list of the node being expanded
     __shared__ int s_cnt[2 * TREE_WAVES];

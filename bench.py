@@ -246,13 +246,16 @@ def config5_leg(games=1000, visits=100, dtype="f16", seed=None):
     wa, wb = model.random_init(12, 128, seed=1), model.random_init(12, 128, seed=2)
     m = arena.Match(wa, wb, visits, games=games, dtype=dtype, seed=selfplay.DEFAULT_SEED if seed is None else seed)
     try:
+        m.set_game_limit(games)   # a slot whose cohort game is over goes idle (uai_ringmaster.py does the same)
         m.run(5)            # first launches (weight packing, kernel load) outside the region
         m.engine.sync()
         st0 = m.engine.stats()
         t0 = time.perf_counter()
-        done, wins, annulled, plies, rounds = 0, {"a": 0.0, "b": 0.0}, 0, 0, 0
+        done, wins, annulled, plies, rounds = 0, {"a": 0.0, "b": 0.0}, 0, 0, 1
+        m.run(25)
         while done < games:
-            m.run(25)
+            m.fetch()
+            m.run(25)       # the next iterations run while the finished games are parsed and scored
             rounds += 1
             for g in m.drain():
                 if g["uid"] >= games:

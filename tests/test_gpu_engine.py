@@ -528,7 +528,7 @@ def test_two_half_batches_in_flight_match_their_oracles_at_bench_size():
         so, sg = oe.stats(), ge.stats()
         for k in so:
             assert so[k] == sg[k], (k, so[k], sg[k])
-        assert sg["ring_overflow"] == 0 and so["plies"] >= ge.G and so["parked"] > 0
+        assert sg["ring_overflow"] == 0 and so["plies"] >= ge.G and sg["parked"] > 0
     assert n_lines > 0
     sp.close()
 

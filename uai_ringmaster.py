@@ -88,11 +88,14 @@ if __name__ == "__main__":
     # while long games still in flight are thrown away — a net that wins quickly would look better than it is; the
     # reference ringmaster plays its games one after another to completion (uai_ringmaster.py:221-262).
     cohort = args.game_count
+    match.set_game_limit(cohort)   # slots whose cohort games are over go idle: the batch thins out towards the end
+    match.run(25)
     while written < cohort:
-        match.run(25)
+        match.fetch()              # the games finished so far ...
+        match.run(25)              # ... are parsed, scored and written under the next iterations
         for game in sorted(match.drain(), key=lambda g: g["uid"]):
             if game["uid"] >= cohort:
-                continue  # a replacement game started in a slot whose cohort games are done
+                continue  # (cannot happen under the game limit; kept for callers that raise the limit)
             white = game["white"]
             black = "b" if white == "a" else "a"
             print('Game: "%s" vs "%s" with opening: [%s]' % (names[white], names[black], ", ".join(game["opening"])))
