@@ -597,6 +597,13 @@ constexpr int RING2 = AZH_RING2;
 #define AZH_OOBZERO 1   /* +1.5 % at 16 K boards, +1.3 % at 3.6 K (profiles/round2_tower_variants.txt, call 9) */
 #endif
 
+// The first layer (4 input planes) as a 1x1 convolution over an im2col image of the planes — K = 9 taps x 4 planes = 36,
+// two k-steps of 32 — instead of nine k-steps (one per tap) that multiply 28 zero channels each: 7 of the tower's 873 k-steps
+// less (model.py:56-57 is the same sum in another order).  0: the first layer walks its nine taps like every other layer.
+#ifndef AZH_FIRST_IM2COL
+#define AZH_FIRST_IM2COL 1
+#endif
+
 template <int DT> struct Mfma16;
 template <> struct Mfma16<AZH_DTYPE_BF16> {
     __device__ static f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
@@ -666,6 +673,63 @@ __device__ constexpr bool skip_pair(int chf, int ct, int inner)
 {
     return (ct == 0 && inner == 0) || (ct == 1 && inner == 2) || (chf == 0 && ct == 4 && inner == 2);
 }
+
+// Epilogue of a variant-2 layer — relu, convert, write 4 channels (8 bytes) per (A tile, cell tile) into image out_img —
+// as TEXT shared by conv_layer2 and first_layer2 (as a function taking the 80 accumulator registers by reference it
+// made the kernel spill 240 of them).  relu after the conversion, on the packed pair: a negative bf16 / f16 is a negative
+// int16, so one packed integer max with 0 clears it (conversion and relu commute: both are monotone and keep the sign).
+// Uses lds, out_img, acc, vmask, cellv, oh, kg, Tr, G, TPW of the enclosing function.
+#if AZH_OOBZERO
+#define AZH_LAYER_EPILOGUE2 \
+    _Pragma("unroll") \
+    for (int ct = 0; ct < TPW; ct++) { \
+        if (!(vmask[ct] & 0x200)) { \
+            const int cellq = cellv[ct] - kg * G::CS + out_img * ((G::NC + G::Z) * G::UB); \
+    _Pragma("unroll") \
+            for (int t = 0; t < 4; t++) { \
+                float v[4]; \
+    _Pragma("unroll") \
+                for (int i = 0; i < 4; i++) \
+                    v[i] = acc[t][ct][i]; \
+                f32x2 lo, hi; \
+                lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3]; \
+                typedef typename Tr::pair pair; \
+                const pair plo = __builtin_convertvector(lo, pair), phi = __builtin_convertvector(hi, pair); \
+                uint2 packed; \
+                typedef short short2v __attribute__((ext_vector_type(2))); \
+                const short2v zero2 = {0, 0}; \
+                packed.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, plo), zero2)); \
+                packed.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, phi), zero2)); \
+                *reinterpret_cast<uint2 *>(lds + cellq + G::ch_off(0, 64 * oh + 16 * t + 4 * kg)) = packed; \
+            } \
+        } \
+    }
+#else
+#define AZH_LAYER_EPILOGUE2 \
+    _Pragma("unroll") \
+    for (int ct = 0; ct < TPW; ct++) { \
+        if (!(cellv[ct] & 0x100)) { \
+            const int cell = cellv[ct]; \
+    _Pragma("unroll") \
+            for (int t = 0; t < 4; t++) { \
+                float v[4]; \
+    _Pragma("unroll") \
+                for (int i = 0; i < 4; i++) \
+                    v[i] = acc[t][ct][i]; \
+                f32x2 lo, hi; \
+                lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3]; \
+                typedef typename Tr::pair pair; \
+                const pair plo = __builtin_convertvector(lo, pair), phi = __builtin_convertvector(hi, pair); \
+                uint2 packed; \
+                typedef short short2v __attribute__((ext_vector_type(2))); \
+                const short2v zero2 = {0, 0}; \
+                packed.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, plo), zero2)); \
+                packed.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, phi), zero2)); \
+                *reinterpret_cast<uint2 *>(lds + G::ch_off(G::real_slot(out_img, cell), 64 * oh + 16 * t + 4 * kg)) = packed; \
+            } \
+        } \
+    }
+#endif
 
 template <int DT, int KS, int CHF, bool STAMP>
 __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, bool skip,
@@ -883,43 +947,81 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             for (int t = 0; t < 4; t++)
                 a[i][t] = tmp[i][t];
     }
-    // epilogue: relu, convert, write 4 channels (8 bytes) per (A tile, cell tile)
+    AZH_LAYER_EPILOGUE2
+    if constexpr (STAMP) st[2] = stamp_now();
+}
+
+#if AZH_FIRST_IM2COL
+// The first layer as a 1x1 convolution over the im2col image of the input planes (built by tower2_run in units 0-7 of image
+// 0: k = 4 tap + plane, zeros for taps that look off the board and for k >= 36): two k-steps, no tap walk, no off-board
+// logic.  Packed A stream of the layer: [step 2][oc tile 8][lane 64][8] (net_pack); the ring holds its two steps on
+// entry and the next layer's first two on exit, like every layer.
+template <int DT, bool STAMP>
+__device__ inline void first_layer2(unsigned char *lds, __amdgpu_buffer_rsrc_t wrsrc, const void *wbase0,
+                                    const typename Traits<DT>::afrag *__restrict__ wp,
+                                    typename Traits<DT>::afrag (&a)[RING2][4], f32x16 &sh, const float *__restrict__ shift_next,
+                                    const int (&vmask)[Geo2::TPW], const int (&cellv)[Geo2::TPW], int wave, int lane,
+                                    unsigned long long *st)
+{
+    typedef Traits<DT> Tr;
+    typedef Geo2 G;
+    typedef typename Tr::afrag afrag;
+    constexpr int TPW = G::TPW;
+    static_assert(RING2 == 2, "the two steps of the im2col layer are the ring");
+    const int kg = lane >> 4;
+    const int oh = wave >> 1;
+    constexpr int out_img = 1;
+    f32x4 acc[4][TPW];
+    f32x4 shq[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            shq[t][i] = sh[4 * t + i];
+    // B fragments of both steps: unit 4 s + kg of the lane's cell (an empty lane reads zeros)
+    afrag b[2][TPW];
 #pragma unroll
     for (int ct = 0; ct < TPW; ct++) {
 #if AZH_OOBZERO
-        if (!(vmask[ct] & 0x200)) {
-            const int cellq = cellv[ct] - kg * G::CS + out_img * ((G::NC + G::Z) * G::UB);  // byte offset of the cell's slot
+        const int base = cellv[ct] + (int)(__builtin_amdgcn_ubfe((unsigned)vmask[ct], 9, 1) << 28);
 #else
-        if (!(cellv[ct] & 0x100)) {
-            const int cell = cellv[ct];
+        const int cell = cellv[ct] & 0xFF;
+        const int base = kg * G::CS + ((cellv[ct] & 0x100) ? G::zero_slot(0, cell) : G::real_slot(0, cell)) * G::UB;
 #endif
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    v[i] = acc[t][ct][i];
-                f32x2 lo, hi;
-                lo[0] = v[0]; lo[1] = v[1]; hi[0] = v[2]; hi[1] = v[3];
-                typedef typename Tr::pair pair;
-                const pair plo = __builtin_convertvector(lo, pair), phi = __builtin_convertvector(hi, pair);
-                uint2 packed;
-                // relu after the conversion, on the packed pair: a negative bf16 / f16 is a negative int16, so one packed
-                // integer max with 0 clears it (conversion and relu commute: both are monotone and keep the sign)
-                typedef short short2v __attribute__((ext_vector_type(2)));
-                const short2v zero2 = {0, 0};
-                packed.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, plo), zero2));
-                packed.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, phi), zero2));
-#if AZH_OOBZERO
-                *reinterpret_cast<uint2 *>(lds + cellq + G::ch_off(0, 64 * oh + 16 * t + 4 * kg)) = packed;
-#else
-                *reinterpret_cast<uint2 *>(lds + G::ch_off(G::real_slot(out_img, cell), 64 * oh + 16 * t + 4 * kg)) = packed;
-#endif
-            }
-        }
+        for (int ks = 0; ks < 2; ks++)
+            b[ks][ct] = *reinterpret_cast<const afrag *>(lds + base + ks * (4 * G::CS));
     }
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const unsigned lane_off = (unsigned)(lane * sizeof(afrag));
+    const unsigned wbyte = (unsigned)(reinterpret_cast<const char *>(wp) - reinterpret_cast<const char *>(wbase0)) +
+                           (unsigned)__builtin_amdgcn_readfirstlane(oh * 4096);
+    if constexpr (STAMP) st[0] = stamp_now();
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int ct = 0; ct < TPW; ct++)
+                acc[t][ct] = Mfma16<DT>::mfma(a[ks][t], b[ks][ct], ks == 0 ? shq[t] : acc[t][ct]);
+        // the next layer's step ks (its stream follows this layer's two steps)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            a[ks][t] = __builtin_bit_cast(afrag, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + t * 1024,
+                                                                                              wbyte + (unsigned)(2 + ks) * 8192u, 0));
+    }
+    if constexpr (STAMP) st[1] = stamp_now();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift_next + 64 * oh + 16 * t + 4 * kg);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            sh[4 * t + i] = t4[i];
+    }
+    AZH_LAYER_EPILOGUE2
     if constexpr (STAMP) st[2] = stamp_now();
 }
+#endif
 
 template <int DT, int CHF, bool STAMP>
 __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int tile0, int nb, int wave, int lane,
@@ -957,13 +1059,21 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
     const afrag *wp = reinterpret_cast<const afrag *>(A.conv_w2);
     // buffer resource over the packed weights (raw 32-bit data, no bounds smaller than the stream; gfx94x/gfx950 word 3)
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A.conv_w2), 0, 0x7FFFFFFF, 0x00020000);
+#if AZH_FIRST_IM2COL
+    const size_t l0 = (size_t)2 * 8 * 64, lf = (size_t)9 * G::KS_FULL * 8 * 64;
+#else
     const size_t l0 = (size_t)9 * G::KS_IN * 8 * 64, lf = (size_t)9 * G::KS_FULL * 8 * 64;
+#endif
     const int oh = wave >> 1, kg = lane >> 4;
     afrag aring[RING2][4];
 #pragma unroll
     for (int i = 0; i < RING2; i++) {
+#if AZH_FIRST_IM2COL
+        const int step = i;  // the im2col layer's two steps
+#else
         // walk position i of the first layer (KS_IN = 1: position = inner tap of row 0)
         const int step = CHF == 0 ? i : 3 * i;
+#endif
 #pragma unroll
         for (int t = 0; t < 4; t++)
             aring[i][t] = wp[((size_t)step * 8 + 4 * oh + t) * 64 + lane];
@@ -977,7 +1087,11 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
             sh[4 * t + i] = t4[i];
     }
     if constexpr (STAMP) st[1] = stamp_now();
+#if AZH_FIRST_IM2COL
+    first_layer2<DT, STAMP>(smem, wrsrc, A.conv_w2, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
+#else
     conv_layer2<DT, G::KS_IN, CHF, STAMP>(smem, 0, 1, false, wrsrc, A.conv_w2, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
+#endif
     __syncthreads();
     if constexpr (STAMP) st[7] = stamp_now();
     wp += l0;
@@ -1022,6 +1136,36 @@ __device__ __forceinline__ void tower2_run(const TowerArgs &A, unsigned char *sm
         *reinterpret_cast<uint4 *>(smem + i) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     // input planes (cpp/self_play_client.cpp:174-202): ones, mover, opponent, blockers
+#if AZH_FIRST_IM2COL
+    // ... as the im2col image the first layer multiplies: for cell c and tap (dx, dy) the four planes of cell (x + dx, y + dy),
+    // zeros off the board; k = 4 tap + plane, i.e. unit tap / 2, bytes 8 (tap & 1) ..; one 16-byte store per (cell, tap pair)
+    for (int item = tid; item < G::NC * 5; item += NTHREADS) {
+        const int u = item / G::NC, cell = item - u * G::NC;
+        int bl, x, y;
+        cell_xy(cell, bl, x, y);
+        if (bl < nb) {
+            int sq0;
+            const int game = tower_src(A, tile0 + bl, x, y, sq0);
+            const unsigned long long mover = A.boards[2 * (size_t)game + 0];
+            const unsigned long long opp = A.boards[2 * (size_t)game + 1];
+            typename Tr::afrag o;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int tap = 2 * u + h;
+                const int xx = x + tap / 3 - 1, yy = y + tap % 3 - 1;
+                const bool on = tap < 9 && xx >= 0 && xx < 7 && yy >= 0 && yy < 7;
+                int sq = 0;
+                if (on)
+                    (void)tower_src(A, tile0 + bl, xx, yy, sq);
+                o[4 * h + 0] = (typename Tr::elem)(on ? 1.0f : 0.0f);
+                o[4 * h + 1] = (typename Tr::elem)(float)(on ? (mover >> sq) & 1ULL : 0ULL);
+                o[4 * h + 2] = (typename Tr::elem)(float)(on ? (opp >> sq) & 1ULL : 0ULL);
+                o[4 * h + 3] = (typename Tr::elem)(float)(on ? (A.blockers >> sq) & 1ULL : 0ULL);
+            }
+            *reinterpret_cast<typename Tr::afrag *>(smem + u * G::CS + G::real_slot(0, cell) * G::UB) = o;
+        }
+    }
+#else
     for (int cell = tid; cell < G::NC; cell += NTHREADS) {
         int bl, x, y;
         cell_xy(cell, bl, x, y);
@@ -1038,6 +1182,7 @@ __device__ __forceinline__ void tower2_run(const TowerArgs &A, unsigned char *sm
             *reinterpret_cast<typename Tr::quad *>(smem + G::ch_off(G::real_slot(0, cell), 0)) = o;
         }
     }
+#endif
     __syncthreads();
     // the two cell halves run separate instantiations: which (tile, tap) pairs are skipped is compile-time
     if (wave & 1)
@@ -1266,7 +1411,19 @@ static int net_pack(azh_net *net, int dt)
             return 0;  // variant 2 (the tuned 16x16x32 tower) is built for 128 filters
         // variant 2
         std::vector<uint16_t> cw2, hw2;
+#if AZH_FIRST_IM2COL
+        // the first layer as a 1x1 convolution over k = 4 tap + plane (36 of 64): [step 2][oc tile 8][lane 64][8]
+        for (int ks = 0; ks < 2; ks++)
+            for (int T = 0; T < 8; T++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < 8; e++) {
+                        const int k = 32 * ks + 8 * (lane >> 4) + e, tap = k / 4, c = k % 4, oc = 16 * T + (lane & 15);
+                        const float v = tap < 9 ? p[((size_t)tap * 4 + c) * F + oc] * sc[oc] : 0.0f;
+                        cw2.push_back(cvt_elem<uint16_t>(v, dt));
+                    }
+#else
         pack_conv16(p, sc, 4, 9, 1, 8, F, dt, cw2);
+#endif
         for (int l = 0; l < 2 * B; l++)
             pack_conv16(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, sc + (size_t)(l + 1) * F, F, 9, 4, 8, F, dt, cw2);
         cw2.resize(cw2.size() + (size_t)RING2 * 8 * 64 * 8, 0);  // the A ring reads RING2 steps past the last layer

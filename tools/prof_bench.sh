@@ -3,7 +3,7 @@
 # kernel trace + stats of the default bench command, then PMC passes for the dominant kernel.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/prof_bench
+OUT=${OUT:-$R/gpurun_out/prof_bench}
 ARGS=${ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-target-leg --no-gemm-ceiling}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -30,9 +30,17 @@ for name in ("k_tower", "k_tree", "k_advance_list"):
     print("rocprofv3 kernel trace, last %d launches (the timed region): %-10s mean %.1f us  p50 %.1f us" % (
         len(d), name, sum(d) / len(d) / 1e3, sorted(d)[len(d) // 2] / 1e3))
 PY
-cat $OUT/timed_region.txt > $OUT/summary_k_tower.txt
+# every summary names the kernel source it measured: bench.py reports roofline.traffic from a committed summary only while
+# the source it names is the source in the tree
+echo "bench.py $ARGS" > $OUT/summary_k_tower.txt
+echo "kernel source sha256: $(sha256sum $R/ataxxzero_amd/csrc/net_kernels.hip | cut -d' ' -f1)  (ataxxzero_amd/csrc/net_kernels.hip)" >> $OUT/summary_k_tower.txt
+cat $OUT/timed_region.txt >> $OUT/summary_k_tower.txt
 python3 $R/tools/prof_summary.py $OUT k_tower >> $OUT/summary_k_tower.txt 2>&1
-for k in k_tree k_advance_list; do python3 $R/tools/prof_summary.py $OUT $k > $OUT/summary_$k.txt 2>&1; done
+for k in k_tree k_advance_list; do
+  echo "bench.py $ARGS" > $OUT/summary_$k.txt
+  echo "kernel source sha256: $(sha256sum $R/ataxxzero_amd/csrc/engine.hip | cut -d' ' -f1)  (ataxxzero_amd/csrc/engine.hip)" >> $OUT/summary_$k.txt
+  python3 $R/tools/prof_summary.py $OUT $k >> $OUT/summary_$k.txt 2>&1
+done
 find $OUT -name "*_counter_collection.csv" -delete
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete
 ls -la $OUT
