@@ -68,6 +68,8 @@ class Match:
         self.games = games
         self.opening_depth = opening_depth
         self.openings = None
+        self.limit = None        # set_game_limit: the size of the match
+        self.finished = 0        # games handed out so far
         if opening_depth > 0:
             # every pairing gets its own random opening, played both ways (uai_ringmaster.py:242-246): slots 2k and 2k + 1
             # start from the same position.  Only the FIRST game of a slot starts from it (uid < games): a match from
@@ -81,6 +83,7 @@ class Match:
         past the limit goes idle instead of starting a game nobody scores, so the batch thins out as the match ends and its
         last, longest games run at the latency of a nearly empty batch (azh_engine_set_game_limit)."""
         self.engine.set_game_limit(games)
+        self.limit = games
 
     def run(self, iterations):
         self.engine.run_arena(self.net_a, self.net_b, iterations, self.dtype)
@@ -103,6 +106,12 @@ class Match:
                 e["moves"] = opening + e["moves"]          # (boards[] starts after the opening; only its last entry is used)
             out.append({"moves": e["moves"], "result": e["result"], "white": white, "uid": e["uid"],
                         "final_score": replay_final_score(e), "boards": e["boards"], "opening": opening})
+        self.finished += len(out)
+        # the match's last games: a handful of leaves per iteration, whose cost is one workgroup's time for the whole net —
+        # from here on the tower runs one board per workgroup (azh_engine_set_thin_batches).  Decided at a drain, by the
+        # count of games handed out: the same point in every run of the same match.
+        if self.limit is not None and self.limit - self.finished <= link.THIN_MAX_GAMES < self.games:
+            self.engine.set_thin_batches(1)
         return out
 
     def close(self):

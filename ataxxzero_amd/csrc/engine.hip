@@ -1595,7 +1595,14 @@ struct azh_engine {
     bool selected = false;
     bool arena_lists = false;  // run_arena: one leaf list per net
     bool stamp_next = false;   // azh_engine_tree_stamps: the next fused tree launch of the loop is the stamped instantiation
+    int thin_mode = -1;        // azh_engine_set_thin_batches: 0 the 3-board tower, 1 one board per workgroup, -1 by the engine's size
 };
+
+// the tower for this engine's leaf batches: one board per workgroup for engines (or batches the host says are) small
+static int thin_batches(const azh_engine *e)
+{
+    return e->thin_mode >= 0 ? e->thin_mode : (e->P.G <= AZH_THIN_MAX_GAMES ? 1 : 0);
+}
 
 static const size_t MAX_TIMED_SAMPLES = 8192;
 
@@ -1823,13 +1830,14 @@ static int launch_eval(azh_engine *e, azh_net *net, int dtype, const int *list, 
 {
     if (!(e->P.flags & AZH_FLAG_SYMMETRY_AVG))
         return azh_net_launch(net, dtype, (const unsigned long long *)e->P.leaf_board, list, count, e->P.G,
-                              e->P.blockers, e->P.logits, e->P.values, e->stream);
+                              e->P.blockers, e->P.logits, e->P.values, e->stream, nullptr, thin_batches(e));
     if (!e->d_sym_logits) {
         AZH_HIP(hipMalloc((void **)&e->d_sym_logits, (size_t)e->P.G * 8 * AZH_POLICY_SIZE * 4));
         AZH_HIP(hipMalloc((void **)&e->d_sym_values, (size_t)e->P.G * 8 * 4));
     }
     return azh_net_launch_sym(net, dtype, (const unsigned long long *)e->P.leaf_board, list, count, e->P.G,
-                              e->P.blockers, e->d_sym_logits, e->d_sym_values, e->P.logits, e->P.values, e->stream);
+                              e->P.blockers, e->d_sym_logits, e->d_sym_values, e->P.logits, e->P.values, e->stream,
+                              e->P.G * 8 <= AZH_THIN_MAX_GAMES || e->thin_mode == 1);
 }
 
 extern "C" int azh_engine_eval(azh_engine *e, azh_net *net, int dtype)
@@ -1925,7 +1933,7 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
         if (net_b && pair)  // both nets' leaf lists in ONE tower launch (1: not applicable -> one after the other)
             rc = azh_net_launch_pair(net_a, net_b, dtype, (const unsigned long long *)e->P.leaf_board, e->P.leaf_list,
                                      e->P.leaf_count, e->P.leaf_list2, e->P.leaf_count2, e->P.G, e->P.blockers, e->P.logits,
-                                     e->P.values, e->stream);
+                                     e->P.values, e->stream, thin_batches(e));
         if (rc == 1) {
             rc = launch_eval(e, net_a, dtype, e->P.leaf_list, e->P.leaf_count);
             if (rc == 0 && net_b)
@@ -1998,6 +2006,14 @@ extern "C" int azh_engine_tree_stamps(azh_engine *e, azh_net *net, int dtype, ui
         return rc;
     AZH_HIP(hipStreamSynchronize(e->stream));
     AZH_HIP(hipMemcpy(out, e->P.stamps, (size_t)e->P.G * TREE_STAMPS * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int azh_engine_set_thin_batches(azh_engine *e, int mode)
+{
+    if (!e || mode < -1 || mode > 1)
+        return azh_fail(-1, "azh_engine_set_thin_batches: mode is -1 (by size), 0 or 1");
+    e->thin_mode = mode;  // (host state only: takes effect with the next launches enqueued)
     return 0;
 }
 

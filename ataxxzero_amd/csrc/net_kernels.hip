@@ -631,6 +631,13 @@ struct Geo2 {
     __device__ static int ch_off(int slot, int ch) { return (ch >> 3) * CS + slot * UB + ((ch & 7) << 1); }
     // value-cell scratch lives in the 10 pad slots of units 0..3
     __device__ static int vcell_off(int c) { return (c / 40) * CS + 310 * UB + (c % 40) * 4; }
+    static constexpr int RING = RING2;            // A-fragment ring depth (k-steps of prefetch distance)
+    static constexpr bool SKIP = true;            // the tile table has edge tiles whose off-board taps are dropped (skip_pair)
+    __device__ static int tile_cell(int tile, int r);  // cell of lane r of cell tile `tile` (TILE_CELL below)
+    static constexpr int NA = 4;                  // 16-channel A tiles per wave: waves 0/1 channels 0-63, waves 2/3 64-127 ...
+    __device__ static int first_channel(int wave) { return 64 * (wave >> 1); }
+    __device__ static int first_a_tile(int wave) { return 4 * (wave >> 1); }
+    __device__ static int first_tile(int wave) { return TPW * (wave & 1); }  // ... even waves cell tiles 0-4, odd 5-9
 };
 
 // Cells of a workgroup are numbered c = 21 y + 7 board + x (the rows of the three boards interleaved), and LDS slot =
@@ -657,6 +664,40 @@ __device__ const unsigned short TILE_CELL[10][16] = {
     {0x060, 0x071, 0x072, 0x073, 0x074, 0x075, 0x066, 0x067, 0x078, 0x079, 0x07a, 0x07b, 0x07c, 0x06d, 0x06e, 0x08f},
 };
 
+__device__ inline int Geo2::tile_cell(int tile, int r) { return TILE_CELL[tile][r]; }
+
+// THIN batches — a match's last games, a UAI engine's single position: a launch of a handful of boards lasts as long as ONE
+// workgroup needs for the 25 layers, and a 3-board workgroup spends that time on 720 MFMAs per wave and layer whether its
+// boards are real or not.  Geo2Thin gives every board a workgroup of its own: the same LDS image (board 0's cells at slots
+// 21 y + x, the other boards' slots unused), four cell tiles instead of ten (49 cells: 16 + 16 + 13 + 4, lane r of a tile
+// again a cell with slot % 16 == r), two per wave, no edge tiles — 288 MFMAs per wave and layer — and a deeper A ring,
+// because with 8 MFMAs per k-step instead of 20 the weight stream from L2 is what a step waits for.  A board's result does
+// not depend on anything but the board (and differs from the 3-board kernel's in the last bits: another summation order).
+#ifndef AZH_RING_THIN
+#define AZH_RING_THIN 6
+#endif
+__device__ const unsigned short TILE_CELL1[4][16] = {
+    {0x000, 0x001, 0x002, 0x003, 0x004, 0x005, 0x006, 0x017, 0x018, 0x019, 0x01a, 0x01b, 0x02c, 0x02d, 0x02e, 0x02f},
+    {0x030, 0x041, 0x042, 0x043, 0x044, 0x015, 0x016, 0x057, 0x058, 0x059, 0x02a, 0x02b, 0x06c, 0x06d, 0x06e, 0x03f},
+    {0x040, 0x081, 0x082, 0x083, 0x054, 0x045, 0x056, 0x107, 0x108, 0x069, 0x05a, 0x06b, 0x10c, 0x10d, 0x07e, 0x06f},
+    {0x080, 0x101, 0x102, 0x103, 0x084, 0x055, 0x106, 0x107, 0x108, 0x109, 0x06a, 0x10b, 0x10c, 0x10d, 0x10e, 0x07f},
+};
+struct Geo2Thin : Geo2 {
+    static constexpr int BOARDS = 1;
+    // every wave takes ALL four cell tiles and 32 of the channels (two A tiles): the same 8 MFMAs per k-step as 4 A tiles x 2
+    // cell tiles, but every A fragment is loaded by one wave only — 8 KB of weights per step and workgroup instead of 16,
+    // which at 64 B per clock from L2 was what a step waited for (0.118 ms per launch with 4 x 2, profiles/round5_thin_tower.txt)
+    static constexpr int NA = 2;
+    static constexpr int TPW = 4;
+    __device__ static int first_channel(int wave) { return 32 * wave; }
+    __device__ static int first_a_tile(int wave) { return 2 * wave; }
+    __device__ static int first_tile(int) { return 0; }
+    static constexpr int RING = AZH_RING_THIN;
+    static constexpr bool SKIP = false;
+    __device__ static int tile_cell(int tile, int r) { return TILE_CELL1[tile][r]; }
+};
+static_assert((3 * Geo2::KS_FULL) % Geo2Thin::RING == 0, "ring phase must be compile-time inside a row");
+
 __device__ inline void cell_xy(int c, int &bl, int &x, int &y)
 {
     y = c / 21;
@@ -678,7 +719,7 @@ __device__ constexpr bool skip_pair(int chf, int ct, int inner)
 // as TEXT shared by conv_layer2 and first_layer2 (as a function taking the 80 accumulator registers by reference it
 // made the kernel spill 240 of them).  relu after the conversion, on the packed pair: a negative bf16 / f16 is a negative
 // int16, so one packed integer max with 0 clears it (conversion and relu commute: both are monotone and keep the sign).
-// Uses lds, out_img, acc, vmask, cellv, oh, kg, Tr, G, TPW of the enclosing function.
+// Uses lds, out_img, acc, vmask, cellv, cbase, kg, NA, Tr, G, TPW of the enclosing function.
 #if AZH_OOBZERO
 #define AZH_LAYER_EPILOGUE2 \
     _Pragma("unroll") \
@@ -686,7 +727,7 @@ __device__ constexpr bool skip_pair(int chf, int ct, int inner)
         if (!(vmask[ct] & 0x200)) { \
             const int cellq = cellv[ct] - kg * G::CS + out_img * ((G::NC + G::Z) * G::UB); \
     _Pragma("unroll") \
-            for (int t = 0; t < 4; t++) { \
+            for (int t = 0; t < NA; t++) { \
                 float v[4]; \
     _Pragma("unroll") \
                 for (int i = 0; i < 4; i++) \
@@ -700,7 +741,7 @@ __device__ constexpr bool skip_pair(int chf, int ct, int inner)
                 const short2v zero2 = {0, 0}; \
                 packed.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, plo), zero2)); \
                 packed.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, phi), zero2)); \
-                *reinterpret_cast<uint2 *>(lds + cellq + G::ch_off(0, 64 * oh + 16 * t + 4 * kg)) = packed; \
+                *reinterpret_cast<uint2 *>(lds + cellq + G::ch_off(0, cbase + 16 * t + 4 * kg)) = packed; \
             } \
         } \
     }
@@ -711,7 +752,7 @@ __device__ constexpr bool skip_pair(int chf, int ct, int inner)
         if (!(cellv[ct] & 0x100)) { \
             const int cell = cellv[ct]; \
     _Pragma("unroll") \
-            for (int t = 0; t < 4; t++) { \
+            for (int t = 0; t < NA; t++) { \
                 float v[4]; \
     _Pragma("unroll") \
                 for (int i = 0; i < 4; i++) \
@@ -725,22 +766,23 @@ __device__ constexpr bool skip_pair(int chf, int ct, int inner)
                 const short2v zero2 = {0, 0}; \
                 packed.x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, plo), zero2)); \
                 packed.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, phi), zero2)); \
-                *reinterpret_cast<uint2 *>(lds + G::ch_off(G::real_slot(out_img, cell), 64 * oh + 16 * t + 4 * kg)) = packed; \
+                *reinterpret_cast<uint2 *>(lds + G::ch_off(G::real_slot(out_img, cell), cbase + 16 * t + 4 * kg)) = packed; \
             } \
         } \
     }
 #endif
 
-template <int DT, int KS, int CHF, bool STAMP>
+template <int DT, int KS, int CHF, bool STAMP, typename G = Geo2>
 __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, bool skip,
                                    __amdgpu_buffer_rsrc_t wrsrc, const void *wbase0,
                                    const typename Traits<DT>::afrag *__restrict__ wp,
-                                   typename Traits<DT>::afrag (&a)[RING2][4], f32x16 &sh, const float *__restrict__ shift_next,
-                                   const int (&vmask)[Geo2::TPW], const int (&cellv)[Geo2::TPW], int wave, int lane,
+                                   typename Traits<DT>::afrag (&a)[G::RING][G::NA], f32x16 &sh, const float *__restrict__ shift_next,
+                                   const int (&vmask)[G::TPW], const int (&cellv)[G::TPW], int wave, int lane,
                                    unsigned long long *st)
 {
     typedef Traits<DT> Tr;
-    typedef Geo2 G;
+    constexpr int RING2 = G::RING;                 // (shadows the global: this geometry's ring depth)
+    auto skip_pair = [](int chf, int ct, int inner) constexpr { return G::SKIP && azh::skip_pair(chf, ct, inner); };
     typedef typename Tr::afrag afrag;
     constexpr int TPW = G::TPW;
     constexpr int TOTAL = 9 * KS;
@@ -748,12 +790,14 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     static_assert(ROW % RING2 == 0 || KS == 1, "ring phase must be compile-time inside a row");
     static_assert(RING2 <= ROW, "the ring prefetch reaches at most one row ahead");
     const int kg = lane >> 4;
-    const int oh = wave >> 1;
+    constexpr int NA = G::NA;                      // 16-channel A tiles per wave
+    const int cbase = G::first_channel(wave);      // the wave's first output channel
+    const int atile0 = G::first_a_tile(wave);      // ... = its first 16-channel A tile
     // accumulators [A tile][cell tile], started at the batch-norm shift (+ residual input)
-    f32x4 acc[4][TPW];
-    f32x4 shq[4];  // the shift of this wave's four channel quads
+    f32x4 acc[NA][TPW];
+    f32x4 shq[NA];  // the shift of this wave's four channel quads
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < NA; t++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
             shq[t][i] = sh[4 * t + i];
@@ -763,13 +807,13 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     const bool first_c = !skip;
     if (!first_c) {
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NA; t++)
 #pragma unroll
             for (int ct = 0; ct < TPW; ct++)
                 acc[t][ct] = shq[t];
     }
     if (skip) {
-        typename Tr::quad sk[4][TPW];
+        typename Tr::quad sk[NA][TPW];
 #pragma unroll
         for (int ct = 0; ct < TPW; ct++) {
 #if AZH_OOBZERO
@@ -777,18 +821,18 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
             const int base = (cellv[ct] - kg * G::CS + out_img * ((G::NC + G::Z) * G::UB)) +
                              (int)(__builtin_amdgcn_ubfe((unsigned)vmask[ct], 9, 1) << 28);
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                sk[t][ct] = *reinterpret_cast<const typename Tr::quad *>(lds + base + G::ch_off(0, 64 * oh + 16 * t + 4 * kg));
+            for (int t = 0; t < NA; t++)
+                sk[t][ct] = *reinterpret_cast<const typename Tr::quad *>(lds + base + G::ch_off(0, cbase + 16 * t + 4 * kg));
 #else
             const int cell = cellv[ct] & 0xFF;
             const int slot = (cellv[ct] & 0x100) ? G::zero_slot(out_img, cell) : G::real_slot(out_img, cell);
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-                sk[t][ct] = *reinterpret_cast<const typename Tr::quad *>(lds + G::ch_off(slot, 64 * oh + 16 * t + 4 * kg));
+            for (int t = 0; t < NA; t++)
+                sk[t][ct] = *reinterpret_cast<const typename Tr::quad *>(lds + G::ch_off(slot, cbase + 16 * t + 4 * kg));
 #endif
         }
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NA; t++)
 #pragma unroll
             for (int ct = 0; ct < TPW; ct++)
 #pragma unroll
@@ -797,25 +841,25 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     }
     auto fetch_shift = [&]() {
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift_next + 64 * oh + 16 * t + 4 * kg);
+        for (int t = 0; t < NA; t++) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift_next + cbase + 16 * t + 4 * kg);
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 sh[4 * t + i] = t4[i];
         }
     };
 
-    // A fragments of packed step s = tap * KS + ks: [s][oc tile 8][lane][8 elements]; this wave reads tiles 4*oh .. 4*oh+3
+    // A fragments of packed step s = tap * KS + ks: [s][oc tile 8][lane][8 elements]; this wave reads tiles atile0 .. atile0 + NA - 1
     const unsigned lane_off = (unsigned)(lane * sizeof(afrag));
     // buffer loads: resource (base of the packed weights) and the step's offset in scalar registers, the lane's 16-B
     // slot in one VGPR, the tile in the immediate — no 64-bit vector address arithmetic in the k-loop
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const unsigned wbyte = (unsigned)(reinterpret_cast<const char *>(wp) - reinterpret_cast<const char *>(wbase0)) +
-                           (unsigned)__builtin_amdgcn_readfirstlane(oh * 4096);
-    auto load_a = [&](afrag (&dst)[4], int step) {
+                           (unsigned)__builtin_amdgcn_readfirstlane(atile0 * 1024);
+    auto load_a = [&](afrag (&dst)[NA], int step) {
         const unsigned soff = wbyte + (unsigned)step * 8192u;
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NA; t++)
             dst[t] = __builtin_bit_cast(afrag, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + t * 1024, soff, 0));
     };
     // (row o, inner i) -> tap = 3 dxi + dyi
@@ -893,7 +937,7 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
                 rows_for(o1, IC<(i + 1) % 3>(), nxt);
             }
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NA; t++)
                 static_for<0, TPW>([&](auto ct_tag) {
                     constexpr int ct = decltype(ct_tag)::value;
                     if constexpr (!skip_pair(CHF, ct, i)) {
@@ -935,16 +979,16 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
     fetch_shift();
     if constexpr (TOTAL % RING2 != 0) {  // rotate so that slot i holds walk position TOTAL + i (next layer's step i)
         constexpr int sh_ = TOTAL % RING2;
-        afrag tmp[RING2][4];
+        afrag tmp[RING2][NA];
 #pragma unroll
         for (int i = 0; i < RING2; i++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NA; t++)
                 tmp[i][t] = a[(i + sh_) % RING2][t];
 #pragma unroll
         for (int i = 0; i < RING2; i++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NA; t++)
                 a[i][t] = tmp[i][t];
     }
     AZH_LAYER_EPILOGUE2
@@ -956,25 +1000,27 @@ __device__ inline void conv_layer2(unsigned char *lds, int in_img, int out_img, 
 // 0: k = 4 tap + plane, zeros for taps that look off the board and for k >= 36): two k-steps, no tap walk, no off-board
 // logic.  Packed A stream of the layer: [step 2][oc tile 8][lane 64][8] (net_pack); the ring holds its two steps on
 // entry and the next layer's first two on exit, like every layer.
-template <int DT, bool STAMP>
+template <int DT, bool STAMP, typename G = Geo2>
 __device__ inline void first_layer2(unsigned char *lds, __amdgpu_buffer_rsrc_t wrsrc, const void *wbase0,
                                     const typename Traits<DT>::afrag *__restrict__ wp,
-                                    typename Traits<DT>::afrag (&a)[RING2][4], f32x16 &sh, const float *__restrict__ shift_next,
-                                    const int (&vmask)[Geo2::TPW], const int (&cellv)[Geo2::TPW], int wave, int lane,
+                                    typename Traits<DT>::afrag (&a)[G::RING][G::NA], f32x16 &sh, const float *__restrict__ shift_next,
+                                    const int (&vmask)[G::TPW], const int (&cellv)[G::TPW], int wave, int lane,
                                     unsigned long long *st)
 {
     typedef Traits<DT> Tr;
-    typedef Geo2 G;
     typedef typename Tr::afrag afrag;
     constexpr int TPW = G::TPW;
-    static_assert(RING2 == 2, "the two steps of the im2col layer are the ring");
+    constexpr int RING2 = G::RING;   // slots 0, 1: this layer's two steps; slots 2 ..: the next layer's first RING - 2
+    static_assert(RING2 >= 2, "the two steps of the im2col layer come out of the ring");
     const int kg = lane >> 4;
-    const int oh = wave >> 1;
+    constexpr int NA = G::NA;                      // 16-channel A tiles per wave
+    const int cbase = G::first_channel(wave);      // the wave's first output channel
+    const int atile0 = G::first_a_tile(wave);      // ... = its first 16-channel A tile
     constexpr int out_img = 1;
-    f32x4 acc[4][TPW];
-    f32x4 shq[4];
+    f32x4 acc[NA][TPW];
+    f32x4 shq[NA];
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < NA; t++)
 #pragma unroll
         for (int i = 0; i < 4; i++)
             shq[t][i] = sh[4 * t + i];
@@ -995,25 +1041,38 @@ __device__ inline void first_layer2(unsigned char *lds, __amdgpu_buffer_rsrc_t w
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const unsigned lane_off = (unsigned)(lane * sizeof(afrag));
     const unsigned wbyte = (unsigned)(reinterpret_cast<const char *>(wp) - reinterpret_cast<const char *>(wbase0)) +
-                           (unsigned)__builtin_amdgcn_readfirstlane(oh * 4096);
+                           (unsigned)__builtin_amdgcn_readfirstlane(atile0 * 1024);
     if constexpr (STAMP) st[0] = stamp_now();
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NA; t++)
 #pragma unroll
             for (int ct = 0; ct < TPW; ct++)
                 acc[t][ct] = Mfma16<DT>::mfma(a[ks][t], b[ks][ct], ks == 0 ? shq[t] : acc[t][ct]);
-        // the next layer's step ks (its stream follows this layer's two steps)
+        // the next layer's step RING - 2 + ks (its stream follows this layer's two steps)
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+        for (int t = 0; t < NA; t++)
             a[ks][t] = __builtin_bit_cast(afrag, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane_off + t * 1024,
-                                                                                              wbyte + (unsigned)(2 + ks) * 8192u, 0));
+                                                                                              wbyte + (unsigned)(RING2 + ks) * 8192u, 0));
+    }
+    if constexpr (RING2 > 2) {  // rotate so that slot i holds the next layer's step i
+        afrag tmp[RING2][NA];
+#pragma unroll
+        for (int i = 0; i < RING2; i++)
+#pragma unroll
+            for (int t = 0; t < NA; t++)
+                tmp[i][t] = a[(i + 2) % RING2][t];
+#pragma unroll
+        for (int i = 0; i < RING2; i++)
+#pragma unroll
+            for (int t = 0; t < NA; t++)
+                a[i][t] = tmp[i][t];
     }
     if constexpr (STAMP) st[1] = stamp_now();
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift_next + 64 * oh + 16 * t + 4 * kg);
+    for (int t = 0; t < NA; t++) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(shift_next + cbase + 16 * t + 4 * kg);
 #pragma unroll
         for (int i = 0; i < 4; i++)
             sh[4 * t + i] = t4[i];
@@ -1023,19 +1082,21 @@ __device__ inline void first_layer2(unsigned char *lds, __amdgpu_buffer_rsrc_t w
 }
 #endif
 
-template <int DT, int CHF, bool STAMP>
+// `tbase`: the wave's first cell tile in the geometry's tile table (G::TPW * CHF where the two wave halves are separate
+// instantiations; a run-time value where one instantiation serves both).
+template <int DT, int CHF, bool STAMP, typename G = Geo2>
 __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int tile0, int nb, int wave, int lane,
-                                   unsigned long long *st)
+                                   unsigned long long *st, int tbase)
 {
     typedef Traits<DT> Tr;
-    typedef Geo2 G;
     typedef typename Tr::afrag afrag;
+    constexpr int RING2 = G::RING;
     int vmask[G::TPW], cellv[G::TPW];
     {
         const int r = lane & 15;
 #pragma unroll
         for (int ct = 0; ct < G::TPW; ct++) {
-            const int cv = TILE_CELL[G::TPW * CHF + ct][r];
+            const int cv = G::tile_cell(tbase + ct, r);
             cellv[ct] = cv;
             int m = 0;
             if (!(cv & 0x100)) {
@@ -1064,8 +1125,9 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
 #else
     const size_t l0 = (size_t)9 * G::KS_IN * 8 * 64, lf = (size_t)9 * G::KS_FULL * 8 * 64;
 #endif
-    const int oh = wave >> 1, kg = lane >> 4;
-    afrag aring[RING2][4];
+    constexpr int NA = G::NA;
+    const int cbase = G::first_channel(wave), atile0 = G::first_a_tile(wave), kg = lane >> 4;
+    afrag aring[RING2][G::NA];
 #pragma unroll
     for (int i = 0; i < RING2; i++) {
 #if AZH_FIRST_IM2COL
@@ -1075,34 +1137,34 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
         const int step = CHF == 0 ? i : 3 * i;
 #endif
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-            aring[i][t] = wp[((size_t)step * 8 + 4 * oh + t) * 64 + lane];
+        for (int t = 0; t < NA; t++)
+            aring[i][t] = wp[((size_t)step * 8 + atile0 + t) * 64 + lane];
     }
     f32x16 sh;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(A.shift + 64 * oh + 16 * t + 4 * kg);
+    for (int t = 0; t < NA; t++) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(A.shift + cbase + 16 * t + 4 * kg);
 #pragma unroll
         for (int i = 0; i < 4; i++)
             sh[4 * t + i] = t4[i];
     }
     if constexpr (STAMP) st[1] = stamp_now();
 #if AZH_FIRST_IM2COL
-    first_layer2<DT, STAMP>(smem, wrsrc, A.conv_w2, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
+    first_layer2<DT, STAMP, G>(smem, wrsrc, A.conv_w2, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
 #else
-    conv_layer2<DT, G::KS_IN, CHF, STAMP>(smem, 0, 1, false, wrsrc, A.conv_w2, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
+    conv_layer2<DT, G::KS_IN, CHF, STAMP, G>(smem, 0, 1, false, wrsrc, A.conv_w2, wp, aring, sh, A.shift + F, vmask, cellv, wave, lane, st + 4);
 #endif
     __syncthreads();
     if constexpr (STAMP) st[7] = stamp_now();
     wp += l0;
     for (int b = 0; b < A.blocks; b++) {
         const float *t1 = A.shift + (size_t)(1 + 2 * b) * F;
-        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 1, 0, false, wrsrc, A.conv_w2, wp, aring, sh, t1 + F, vmask, cellv, wave, lane,
+        conv_layer2<DT, G::KS_FULL, CHF, STAMP, G>(smem, 1, 0, false, wrsrc, A.conv_w2, wp, aring, sh, t1 + F, vmask, cellv, wave, lane,
                                                 st + 8 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) st[8 + 8 * b + 3] = stamp_now();
         wp += lf;
-        conv_layer2<DT, G::KS_FULL, CHF, STAMP>(smem, 0, 1, true, wrsrc, A.conv_w2, wp, aring, sh, t1 + 2 * F, vmask, cellv, wave, lane,
+        conv_layer2<DT, G::KS_FULL, CHF, STAMP, G>(smem, 0, 1, true, wrsrc, A.conv_w2, wp, aring, sh, t1 + 2 * F, vmask, cellv, wave, lane,
                                                 st + 12 + 8 * b);
         __syncthreads();
         if constexpr (STAMP) {
@@ -1115,11 +1177,10 @@ __device__ inline void tower2_body(const TowerArgs &A, unsigned char *smem, int 
 }
 
 // The whole net for the workgroup's boards tile0 .. tile0 + 2 of the n (virtual) boards A lists.
-template <int DT, bool STAMP = false>
+template <int DT, bool STAMP = false, typename G = Geo2>
 __device__ __forceinline__ void tower2_run(const TowerArgs &A, unsigned char *smem, int tile0, int n)
 {
     typedef Traits<DT> Tr;
-    typedef Geo2 G;
     typedef typename Tr::afrag afrag;
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is the same in all 64 lanes: say so, and everything derived from it (the weight stream's base
@@ -1185,10 +1246,15 @@ __device__ __forceinline__ void tower2_run(const TowerArgs &A, unsigned char *sm
 #endif
     __syncthreads();
     // the two cell halves run separate instantiations: which (tile, tap) pairs are skipped is compile-time
-    if (wave & 1)
-        tower2_body<DT, 1, STAMP>(A, smem, tile0, nb, wave, lane, st);
-    else
-        tower2_body<DT, 0, STAMP>(A, smem, tile0, nb, wave, lane, st);
+    if constexpr (G::SKIP) {
+        if (wave & 1)
+            tower2_body<DT, 1, STAMP, G>(A, smem, tile0, nb, wave, lane, st, G::TPW);
+        else
+            tower2_body<DT, 0, STAMP, G>(A, smem, tile0, nb, wave, lane, st, 0);
+    } else {
+        // no compile-time fact depends on the wave half: one instantiation, the half picks the tiles
+        tower2_body<DT, 0, STAMP, G>(A, smem, tile0, nb, wave, lane, st, G::first_tile(wave));
+    }
     // heads: two 16-row A tiles (policy 0-15 | policy 16, value conv, pad); cell tiles dealt to the waves
     {
         const afrag *hp = reinterpret_cast<const afrag *>(A.head_w2) + lane;
@@ -1249,18 +1315,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
     tower2_run<DT, STAMP>(A, smem, tile0, n);
 }
 
+template <int DT>
+__global__ __launch_bounds__(NTHREADS, 2) void k_tower2_thin(TowerArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
+    const int tile0 = blockIdx.x;
+    if (tile0 >= n)
+        return;
+    tower2_run<DT, false, Geo2Thin>(A, smem, tile0, n);
+}
+
 // Two nets in ONE launch (arena, uai_ringmaster.py:221-265: every position is searched by the net whose move it is): the
 // first ceil(nA / 3) workgroups evaluate list A with net A's weights, the following ceil(nB / 3) list B with net B's.
 // Everything that differs between the two — weights, shifts, value head, list, count, block count — is picked once per
 // workgroup from the kernel arguments with scalar selects (blockIdx is uniform); the body is the one k_tower2 runs, so a
 // board's result is bit for bit that of the single-net launch.  Two third-full launches back to back become one launch
 // whose workgroups all start together: at 2 x 500 leaves the iteration's evaluator time halves.
-template <int DT>
+template <int DT, typename G = Geo2>
 __global__ __launch_bounds__(NTHREADS, 2) void k_tower2_pair(TowerArgs A, TowerArgs B)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int na = *A.count;
-    const int wga = (na + Geo2::BOARDS - 1) / Geo2::BOARDS;
+    const int wga = (na + G::BOARDS - 1) / G::BOARDS;
     const bool second = (int)blockIdx.x >= wga;
     TowerArgs X = A;
     if (second) {
@@ -1273,10 +1350,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2_pair(TowerArgs A, TowerA
         X.list = B.list;
     }
     const int n = second ? *B.count : na;
-    const int tile0 = ((int)blockIdx.x - (second ? wga : 0)) * Geo2::BOARDS;
+    const int tile0 = ((int)blockIdx.x - (second ? wga : 0)) * G::BOARDS;
     if (tile0 >= n)
         return;
-    tower2_run<DT, false>(X, smem, tile0, n);
+    tower2_run<DT, false, G>(X, smem, tile0, n);
 }
 
 // ------------------------------------------------------------------ host side
@@ -1426,7 +1503,8 @@ static int net_pack(azh_net *net, int dt)
 #endif
         for (int l = 0; l < 2 * B; l++)
             pack_conv16(p + (size_t)9 * 4 * F + (size_t)l * 9 * F * F, sc + (size_t)(l + 1) * F, F, 9, 4, 8, F, dt, cw2);
-        cw2.resize(cw2.size() + (size_t)RING2 * 8 * 64 * 8, 0);  // the A ring reads RING2 steps past the last layer
+        // the A ring reads its depth in steps past the last layer (the thin geometry's ring is the deeper one)
+        cw2.resize(cw2.size() + (size_t)(RING2 > AZH_RING_THIN ? RING2 : AZH_RING_THIN) * 8 * 64 * 8, 0);
         pack_conv16(head.data(), nullptr, F, 1, 4, 2, 32, dt, hw2);
         if (upload(cw2.data(), cw2.size() * 2, &net->bufs[dt].conv_w2)) return -1;
         if (upload(hw2.data(), hw2.size() * 2, &net->bufs[dt].head_w2)) return -1;
@@ -1604,6 +1682,24 @@ template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &
     return 0;
 }
 
+// one board per workgroup (Geo2Thin): the launch for a handful of boards
+template <int DT> static int launch_tower2_thin(const TowerArgs &args, int max_n, hipStream_t stream)
+{
+    static bool attr_set[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0)
+        return azh_fail(-4, "launch_tower2_thin: hipGetDevice failed");
+    if (!attr_set[dev]) {
+        AZH_HIP(hipFuncSetAttribute((const void *)k_tower2_thin<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo2::LDS_BYTES));
+        attr_set[dev] = true;
+    }
+    if (max_n <= 0)
+        return 0;
+    hipLaunchKernelGGL((k_tower2_thin<DT>), dim3(max_n), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args);
+    AZH_HIP(hipGetLastError());
+    return 0;
+}
+
 // The 16-bit towers run variant 2 (16x16x32 MFMA, 64 channels per wave); AZH_TOWER=1 selects
 // variant 1 (32x32x16, 32 channels per wave), which is also the f32 tower's shape.
 static int tower_variant()
@@ -1662,25 +1758,26 @@ __global__ __launch_bounds__(256) void k_sym_reduce(const float *__restrict__ sy
 // first n boards when both are null).  Everything is indexed by game.
 static int net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                       const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym);
+                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym, int thin = 0);
 
+// thin: the caller expects a handful of boards (<= 512): one board per workgroup (Geo2Thin) where that kernel applies
 int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                    const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                   float *d_values, hipStream_t stream, unsigned long long *d_stamps)
+                   float *d_values, hipStream_t stream, unsigned long long *d_stamps, int thin)
 {
-    return net_launch(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_logits, d_values, stream, d_stamps, 0);
+    return net_launch(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_logits, d_values, stream, d_stamps, 0, thin);
 }
 
 // Symmetry-averaged evaluation: the tower runs 8 * n virtual boards into the scratch arrays
 // (d_tmp_logits [8 max_n][833], d_tmp_values [8 max_n]), k_sym_reduce writes the averages by game.
 int azh_net_launch_sym(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                        const int *d_count, int max_n, unsigned long long blockers, float *d_tmp_logits,
-                       float *d_tmp_values, float *d_logits, float *d_values, hipStream_t stream)
+                       float *d_tmp_values, float *d_logits, float *d_values, hipStream_t stream, int thin)
 {
     if (max_n <= 0)
         return 0;
     int rc = net_launch(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_tmp_logits, d_tmp_values, stream,
-                        nullptr, 1);
+                        nullptr, 1, thin);
     if (rc)
         return rc;
     hipLaunchKernelGGL(k_sym_reduce, dim3(max_n), dim3(256), 0, stream, (const float *)d_tmp_logits,
@@ -1719,7 +1816,7 @@ static TowerArgs tower_args(const azh_net *net, int dtype, const unsigned long l
 // then launches the two nets one after the other.  max_n bounds count_a + count_b (a game has one leaf).
 int azh_net_launch_pair(azh_net *net_a, azh_net *net_b, int dtype, const unsigned long long *d_boards, const int *d_list_a,
                         const int *d_count_a, const int *d_list_b, const int *d_count_b, int max_n,
-                        unsigned long long blockers, float *d_logits, float *d_values, hipStream_t stream)
+                        unsigned long long blockers, float *d_logits, float *d_values, hipStream_t stream, int thin)
 {
     if (dtype != AZH_DTYPE_BF16 && dtype != AZH_DTYPE_F16)
         return 1;
@@ -1733,29 +1830,32 @@ int azh_net_launch_pair(azh_net *net_a, azh_net *net_b, int dtype, const unsigne
         return -1;
     const TowerArgs a = tower_args(net_a, dtype, d_boards, d_list_a, d_count_a, max_n, blockers, d_logits, d_values, nullptr, 0);
     const TowerArgs b = tower_args(net_b, dtype, d_boards, d_list_b, d_count_b, max_n, blockers, d_logits, d_values, nullptr, 0);
-    static bool attr_set[MAX_DEVICES][2] = {};
+    static bool attr_set[MAX_DEVICES][4] = {};
     const int dev = current_device();
     if (dev < 0)
         return azh_fail(-4, "azh_net_launch_pair: hipGetDevice failed");
-    const int k = dtype == AZH_DTYPE_BF16 ? 0 : 1;
+    const int k = (dtype == AZH_DTYPE_BF16 ? 0 : 1) + (thin ? 2 : 0);
+    const void *fn = k == 0 ? (const void *)k_tower2_pair<AZH_DTYPE_BF16> : k == 1 ? (const void *)k_tower2_pair<AZH_DTYPE_F16>
+                   : k == 2 ? (const void *)k_tower2_pair<AZH_DTYPE_BF16, Geo2Thin> : (const void *)k_tower2_pair<AZH_DTYPE_F16, Geo2Thin>;
     if (!attr_set[dev][k]) {
-        AZH_HIP(hipFuncSetAttribute(k == 0 ? (const void *)k_tower2_pair<AZH_DTYPE_BF16> : (const void *)k_tower2_pair<AZH_DTYPE_F16>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, Geo2::LDS_BYTES));
+        AZH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, Geo2::LDS_BYTES));
         attr_set[dev][k] = true;
     }
-    // ceil(nA / 3) + ceil(nB / 3) <= (nA + nB) / 3 + 2 workgroups
-    const int grid = max_n / Geo2::BOARDS + 2;
-    if (k == 0)
-        hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b);
-    else
-        hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b);
+    // ceil(nA / B) + ceil(nB / B) <= (nA + nB) / B + 2 workgroups of B boards (B = 3, or 1 for thin batches)
+    const int grid = max_n / (thin ? Geo2Thin::BOARDS : Geo2::BOARDS) + 2;
+    switch (k) {
+    case 0: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b); break;
+    case 1: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b); break;
+    case 2: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16, Geo2Thin>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b); break;
+    default: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16, Geo2Thin>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b); break;
+    }
     AZH_HIP(hipGetLastError());
     return 0;
 }
 
 static int net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                       const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym)
+                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym, int thin)
 {
     if (dtype < 0 || dtype > 2)
         return azh_fail(-2, "bad dtype %d", dtype);
@@ -1792,6 +1892,9 @@ static int net_launch(azh_net *net, int dtype, const unsigned long long *d_board
         if (d_stamps)
             return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16, true>(a, max_n, stream)
                                            : azh_fail(-2, "stamps are built for bf16 only");
+        if (thin)
+            return dtype == AZH_DTYPE_BF16 ? launch_tower2_thin<AZH_DTYPE_BF16>(a, max_n, stream)
+                                           : launch_tower2_thin<AZH_DTYPE_F16>(a, max_n, stream);
         return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16>(a, max_n, stream)
                                        : launch_tower2<AZH_DTYPE_F16>(a, max_n, stream);
     }
@@ -1821,8 +1924,23 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
 };
 
+static int net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards, uint64_t blockers, float *logits_out,
+                       float *values_out, int thin);
+
 extern "C" int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards,
                                uint64_t blockers, float *logits_out, float *values_out)
+{
+    return net_forward(net, dtype, n, leaf_boards, blockers, logits_out, values_out, 0);
+}
+
+extern "C" int azh_net_forward_thin(azh_net *net, int dtype, int n, const uint64_t *leaf_boards,
+                                    uint64_t blockers, float *logits_out, float *values_out)
+{
+    return net_forward(net, dtype, n, leaf_boards, blockers, logits_out, values_out, 1);
+}
+
+static int net_forward(azh_net *net, int dtype, int n, const uint64_t *leaf_boards, uint64_t blockers, float *logits_out,
+                       float *values_out, int thin)
 {
     if (!net || !leaf_boards || !logits_out || !values_out || n < 0)
         return azh_fail(-1, "azh_net_forward: bad argument");
@@ -1834,7 +1952,7 @@ extern "C" int azh_net_forward(azh_net *net, int dtype, int n, const uint64_t *l
     AZH_HIP(d_v.alloc((size_t)n * 4));
     AZH_HIP(hipMemcpy(d_b.p, leaf_boards, (size_t)n * 16, hipMemcpyHostToDevice));
     const int rc = azh_net_launch(net, dtype, d_b.as<unsigned long long>(), nullptr, nullptr, n, blockers, d_l.as<float>(),
-                                  d_v.as<float>(), 0, nullptr);
+                                  d_v.as<float>(), 0, nullptr, thin);
     if (rc)
         return rc;
     AZH_HIP(hipDeviceSynchronize());
@@ -1869,7 +1987,11 @@ extern "C" int azh_net_forward_sym(azh_net *net, int dtype, int n, const uint64_
 
 // Net-only timing hook: `iters` launches of the tower over n synthetic boards, HIP-event
 // timed on one stream; *ms_out = average milliseconds per launch.
-extern "C" int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out)
+static int net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out, int thin);
+extern "C" int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out) { return net_bench(net, dtype, n, iters, ms_out, 0); }
+extern "C" int azh_net_bench_thin(azh_net *net, int dtype, int n, int iters, float *ms_out) { return net_bench(net, dtype, n, iters, ms_out, 1); }
+
+static int net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out, int thin)
 {
     if (!net || n <= 0 || iters <= 0 || !ms_out)
         return azh_fail(-1, "azh_net_bench: bad argument");
@@ -1895,10 +2017,10 @@ extern "C" int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *m
     AZH_HIP(hipEventCreate(&e1));
     int rc = 0;
     for (int i = 0; i < 3 && rc == 0; i++)
-        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st, nullptr);
+        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st, nullptr, thin);
     AZH_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters && rc == 0; i++)
-        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st, nullptr);
+        rc = azh_net_launch(net, dtype, d_b, nullptr, nullptr, n, 0, d_l, d_v, st, nullptr, thin);
     AZH_HIP(hipEventRecord(e1, st));
     AZH_HIP(hipStreamSynchronize(st));
     float ms = 0.0f;

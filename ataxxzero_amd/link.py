@@ -19,6 +19,7 @@ POLICY_SIZE = 833
 FEATURE_SIZE = 196
 MAX_MOVES = 256
 STAT_COUNT = 16
+THIN_MAX_GAMES = 512        # AZH_THIN_MAX_GAMES: engines of at most this many game slots evaluate with one board per workgroup
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, "bf16": DTYPE_BF16,
           "f16": DTYPE_F16, "fp16": DTYPE_F16}
@@ -79,6 +80,8 @@ SIGNATURES = {
     "azh_net_forward": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
     "azh_net_forward_sym": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
     "azh_net_bench": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P(_f32)]),
+    "azh_net_forward_thin": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _u64, _vp, _vp]),
+    "azh_net_bench_thin": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P(_f32)]),
     "azh_net_stamps": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     "azh_engine_create": (ctypes.c_int, [_P(Config), _P(_vp)]),
     "azh_engine_destroy": (None, [_vp]),
@@ -94,6 +97,7 @@ SIGNATURES = {
     "azh_engine_run_arena": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     "azh_engine_sync": (ctypes.c_int, [_vp]),
     "azh_engine_set_visits": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "azh_engine_set_thin_batches": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_game_state": (ctypes.c_int, [_vp, ctypes.c_int, _P(GameState)]),
     "azh_engine_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "azh_engine_stats": (ctypes.c_int, [_vp, _vp]),
@@ -270,12 +274,14 @@ class Net:
         check(load().azh_net_create(blocks, filters, _ptr(conv_flat), _ptr(bn_flat), bn_eps, ctypes.byref(h)))
         self.h = h
 
-    def forward(self, leaf_boards, blockers, dtype=DTYPE_BF16):
+    def forward(self, leaf_boards, blockers, dtype=DTYPE_BF16, thin=False):
+        """thin: one board per workgroup (the kernel for a handful of boards, azh_net_forward_thin)."""
         leaf_boards = np.ascontiguousarray(leaf_boards, dtype=np.uint64).reshape(-1, 2)
         n = len(leaf_boards)
         logits = np.zeros((n, 7, 7, 17), dtype=np.float32)
         values = np.zeros((n, 1), dtype=np.float32)
-        check(load().azh_net_forward(self.h, dtype, n, _ptr(leaf_boards), int(blockers), _ptr(logits), _ptr(values)))
+        fn = load().azh_net_forward_thin if thin else load().azh_net_forward
+        check(fn(self.h, dtype, n, _ptr(leaf_boards), int(blockers), _ptr(logits), _ptr(values)))
         return logits, values
 
     def forward_sym(self, leaf_boards, blockers, dtype=DTYPE_BF16):
@@ -287,10 +293,10 @@ class Net:
         check(load().azh_net_forward_sym(self.h, dtype, n, _ptr(leaf_boards), int(blockers), _ptr(logits), _ptr(values)))
         return logits, values
 
-    def bench(self, n, iters=20, dtype=DTYPE_BF16):
+    def bench(self, n, iters=20, dtype=DTYPE_BF16, thin=False):
         """Average milliseconds per tower launch over n synthetic boards."""
         ms = ctypes.c_float(0)
-        check(load().azh_net_bench(self.h, dtype, n, iters, ctypes.byref(ms)))
+        check((load().azh_net_bench_thin if thin else load().azh_net_bench)(self.h, dtype, n, iters, ctypes.byref(ms)))
         return float(ms.value)
 
     def stamps(self, n, wgs=64):
@@ -375,6 +381,10 @@ class Engine:
 
     def set_visits(self, visits):
         check(load().azh_engine_set_visits(self.h, visits))
+
+    def set_thin_batches(self, mode):
+        """0: the 3-board tower; 1: one board per workgroup (a handful of leaves per iteration); -1: by the engine's size."""
+        check(load().azh_engine_set_thin_batches(self.h, int(mode)))
 
     def set_positions(self, boards, plies):
         """Every slot restarts at boards[g] (packed x | turn << 63, o) / plies[g] with a fresh tree (counted, not written)."""

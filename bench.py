@@ -239,10 +239,12 @@ def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=No
 def config5_leg(games=1000, visits=100, dtype="f16", seed=None):
     """BASELINE configs[4] (uai_ringmaster.py with two uai_interface.py engines, :75-160,221-265) through this repo's batched
     arena: a FIXED cohort of `games` games — every pairing both ways — between two random-init 12x128 nets (seeds 1 and 2),
-    `visits` MCTS steps per move from a fresh tree, played to completion as uai_ringmaster.py's drop-in plays it (25 search
-    iterations per round trip, finished games drained and scored).  The wall time is the longest game of the cohort at the
+    `visits` MCTS steps per move from a fresh tree, played to completion as uai_ringmaster.py's drop-in plays it (50 search
+    iterations per round trip, finished games drained and scored; thin batches — one board per workgroup — once at most 512
+    games of the match are left).  The wall time is the longest game of the cohort at the
     latency of a thinning batch; the rates are whole-cohort figures."""
     from ataxxzero_amd import arena, model, selfplay
+    ROUND = 50   # search iterations per host round trip (uai_ringmaster.py's drop-in uses the same)
     wa, wb = model.random_init(12, 128, seed=1), model.random_init(12, 128, seed=2)
     m = arena.Match(wa, wb, visits, games=games, dtype=dtype, seed=selfplay.DEFAULT_SEED if seed is None else seed)
     try:
@@ -252,10 +254,10 @@ def config5_leg(games=1000, visits=100, dtype="f16", seed=None):
         st0 = m.engine.stats()
         t0 = time.perf_counter()
         done, wins, annulled, plies, rounds = 0, {"a": 0.0, "b": 0.0}, 0, 0, 1
-        m.run(25)
+        m.run(ROUND)
         while done < games:
             m.fetch()
-            m.run(25)       # the next iterations run while the finished games are parsed and scored
+            m.run(ROUND)    # the next iterations run while the finished games are parsed and scored
             rounds += 1
             for g in m.drain():
                 if g["uid"] >= games:
@@ -280,7 +282,7 @@ def config5_leg(games=1000, visits=100, dtype="f16", seed=None):
                             "nets (seeds 1, 2), %d visits/move, %s, all games in flight from the start" % (games, visits, dtype),
                 "games": done, "wall_s": dt, "games_per_s": done / dt, "mcts_steps_per_s": d["steps"] / dt,
                 "nn_evals_per_s": d["nn_evals"] / dt, "plies_per_s": d["plies"] / dt, "mean_plies": plies / float(max(done, 1)),
-                "search_iterations": 25 * rounds, "ms_per_iteration": 1e3 * dt / (25 * rounds),
+                "search_iterations": ROUND * rounds, "ms_per_iteration": 1e3 * dt / (ROUND * rounds),
                 "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[dtype],
                 "two_nets_in_one_launch": os.environ.get("AZH_ARENA_PAIR", "1") != "0",
                 "score": "%s - %s (annulled: %d)" % (wins["a"], wins["b"], annulled),

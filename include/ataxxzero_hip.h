@@ -112,6 +112,15 @@ int azh_net_forward_sym(azh_net *net, int dtype, int n, const uint64_t *leaf_boa
 /* Measurement hook: average HIP-event milliseconds per launch of the tower kernel over
  * n synthetic boards (iters launches on one stream, 3 untimed warm-up launches). */
 int azh_net_bench(azh_net *net, int dtype, int n, int iters, float *ms_out);
+/* THIN batches (a match's last games, a UAI engine's single position): the 16-bit towers with ONE board per workgroup — the
+ * latency of a launch of a handful of boards is one workgroup's time for the 25 layers, and a board alone in its workgroup
+ * needs 288 MFMAs per wave and layer instead of the 3-board workgroup's 720.  Same net, same boards -> the same logits and
+ * values up to the summation order (the last bits of the 16-bit towers differ from the 3-board kernel's); f32 and other
+ * widths run the ordinary tower.  azh_net_forward_thin / azh_net_bench_thin: azh_net_forward / azh_net_bench through that
+ * kernel. */
+int azh_net_forward_thin(azh_net *net, int dtype, int n, const uint64_t *leaf_boards, uint64_t blockers,
+                         float *logits_out, float *values_out);
+int azh_net_bench_thin(azh_net *net, int dtype, int n, int iters, float *ms_out);
 /* Diagnostic build of the bf16 tower with s_memtime stamps per layer phase: copies the
  * stamps of the first `wgs` workgroups, [wg][wave][128] u64, to out (layout: net_kernels.hip). */
 int azh_net_stamps(azh_net *net, int n, int wgs, uint64_t *out);
@@ -223,6 +232,13 @@ int azh_engine_sync(azh_engine *e);
 /* change the root-visit threshold (global_visits) for the coming moves; 1 <= visits <= the
  * value the engine was created with */
 int azh_engine_set_visits(azh_engine *e, int visits);
+/* Which tower the device-resident loop evaluates its leaves with: 0 the 3-board workgroups (throughput), 1 one board per
+ * workgroup (latency: azh_net_forward_thin's kernel), -1 (default) by the engine's size — thin for engines of at most
+ * AZH_THIN_MAX_GAMES game slots.  A host that knows its batch has thinned out (a match under a game limit whose last games
+ * are running, uai_ringmaster.py:221-262) switches at a drain; results of the 16-bit towers differ in the last bits between
+ * the two kernels, so switch at points that do not depend on timing. */
+#define AZH_THIN_MAX_GAMES 512
+int azh_engine_set_thin_batches(azh_engine *e, int mode);
 
 /* Measurement set-up hook: every slot restarts at a given position — boards [games][2] packed (x | turn << 63, o),
  * plies [games] — with a fresh tree.  Such games are played, counted (AZH_STAT_GAMES / _DROPPED), and their records are

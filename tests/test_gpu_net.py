@@ -279,6 +279,34 @@ def test_symmetry_averaged_forward_matches_nn_evals_restatement():
     assert p0.shape == (0, 7, 7, 17)
 
 
+@pytest.mark.parametrize("dtype,tol", [(link.DTYPE_BF16, 2e-3), (link.DTYPE_F16, 3e-4)])
+def test_thin_tower_equals_the_three_board_tower_to_rounding_and_is_position_independent(dtype, tol):
+    """One board per workgroup (azh_net_forward_thin: the kernel for a match's last games and a UAI engine's single
+    position) computes model.Network's forward (model.py:38-79) for the same boards: equal to the 3-board tower within the
+    16-bit towers' own rounding (another summation order), bounded against the f32 tower like it, and bit-identical
+    wherever a board sits in the launch and whatever is beside it — empty batch, one board, a ragged count."""
+    conv, bn = model.random_init(12, 128, seed=1, perturb_bn=True)
+    net = link.Net(conv, bn)
+    boards = sample_leaf_boards(301, 5, BLOCK4_MASK)
+    p3, v3 = net.forward(boards, BLOCK4_MASK, dtype)
+    p1, v1 = net.forward(boards, BLOCK4_MASK, dtype, thin=True)
+    pf, vf = net.forward(boards, BLOCK4_MASK, link.DTYPE_F32)
+    assert np.abs(p1 - p3).max() <= tol and np.abs(v1 - v3).max() <= tol
+    assert np.abs(p1 - pf).max() <= np.abs(p3 - pf).max() * 1.5 + 1e-6 and np.abs(v1 - vf).max() <= np.abs(v3 - vf).max() * 1.5 + 1e-6
+    # any order, any neighbours: the same bits
+    perm = np.random.default_rng(3).permutation(len(boards))
+    pq, vq = net.forward(boards[perm], BLOCK4_MASK, dtype, thin=True)
+    assert (pq == p1[perm]).all() and (vq == v1[perm]).all()
+    for lo, n in ((0, 1), (7, 2), (100, 37)):
+        ps, vs = net.forward(boards[lo:lo + n], BLOCK4_MASK, dtype, thin=True)
+        assert (ps == p1[lo:lo + n]).all() and (vs == v1[lo:lo + n]).all()
+    pe, ve = net.forward(boards[:0], BLOCK4_MASK, dtype, thin=True)
+    assert pe.shape[0] == 0 and ve.shape[0] == 0
+    # f32 has no thin kernel: the call runs the ordinary f32 tower
+    pt, vt = net.forward(boards[:9], BLOCK4_MASK, link.DTYPE_F32, thin=True)
+    assert (pt == pf[:9]).all() and (vt == vf[:9]).all()
+
+
 @pytest.mark.parametrize("dtype", [link.DTYPE_BF16, link.DTYPE_F16, link.DTYPE_F32])
 def test_full_size_launch_is_position_independent(dtype):
     """A 16384-board launch (the bench's largest): a board's logits and value do not depend on which workgroup

@@ -89,10 +89,10 @@ if __name__ == "__main__":
     # reference ringmaster plays its games one after another to completion (uai_ringmaster.py:221-262).
     cohort = args.game_count
     match.set_game_limit(cohort)   # slots whose cohort games are over go idle: the batch thins out towards the end
-    match.run(25)
+    match.run(50)
     while written < cohort:
         match.fetch()              # the games finished so far ...
-        match.run(25)              # ... are parsed, scored and written under the next iterations
+        match.run(50)              # ... are parsed, scored and written under the next iterations
         for game in sorted(match.drain(), key=lambda g: g["uid"]):
             if game["uid"] >= cohort:
                 continue  # (cannot happen under the game limit; kept for callers that raise the limit)
