@@ -106,6 +106,12 @@ class SelfPlay:
         for e in self.engines:
             e.set_visits(visits)
 
+    def set_thin_batches(self, mode):
+        """1: the towers run one board per workgroup (a handful of leaves per iteration: the tail of a run under a game
+        limit); 0: the 3-board workgroups; -1: by each engine's size (link.Engine.set_thin_batches)."""
+        for e in self.engines:
+            e.set_thin_batches(mode)
+
     def set_positions(self, boards, plies):
         lo = 0
         for e in self.engines:

@@ -56,6 +56,9 @@ class FakeSelfPlay:
         self.limit = n
         calls.append(["limit", n])
 
+    def set_thin_batches(self, mode):
+        calls.append(["thin", mode])
+
     def run(self, iterations):
         calls.append(["run", iterations])
         self.unfetched_work = True
