@@ -8,12 +8,12 @@ python3 -c "
 from ataxxzero_amd import model
 conv, bn = model.random_init(12, 128, seed=1)
 model.save_model('/tmp/thin-ab.npy', conv, bn)"
-for mode in thin three_boards thin three_boards; do
+for mode in ${MODES:-thin three_boards thin three_boards}; do
   rm -f /tmp/thin-ab-$mode.json
   if [ $mode = three_boards ]; then export AZH_NO_THIN_TAIL=1; else unset AZH_NO_THIN_TAIL; fi
   t0=$(date +%s.%N)
   timeout -k 10 400 python3 accelerated_generate_games.py --network /tmp/thin-ab.npy --output-games /tmp/thin-ab-$mode.json --visits 400 \
-      --buffer-size 1024 --game-count $N --seed 77 > /tmp/thin-ab-$mode.log 2>&1 || { tail -3 /tmp/thin-ab-$mode.log; exit 1; }
+      --buffer-size ${BUF:-1024} --game-count $N --seed 77 > /tmp/thin-ab-$mode.log 2>&1 || { tail -3 /tmp/thin-ab-$mode.log; exit 1; }
   t1=$(date +%s.%N)
   echo "$mode: $N games in $(python3 -c "print('%.1f' % ($t1-$t0))") s (process start and weight packing included); $(grep Totals /tmp/thin-ab-$mode.log | python3 -c "
 import json,sys
