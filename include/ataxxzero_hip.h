@@ -226,7 +226,11 @@ int azh_engine_backup(azh_engine *e);
 /* `iterations` full iterations with the built-in net, enqueued asynchronously */
 int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations);
 /* arena (AZH_FLAG_TWO_NETS): net_a plays x in even slots and o in odd slots, net_b the
- * other way round (uai_ringmaster.py:241-247 queues every pairing both ways) */
+ * other way round (uai_ringmaster.py:241-247 queues every pairing both ways).  Per iteration the leaves whose mover is net_a and
+ * those whose mover is net_b are evaluated by ONE launch of the 16-bit tower (each workgroup picks its weight set from the list
+ * it serves; the nets may differ in depth; f32, other widths and AZH_FLAG_SYMMETRY_AVG: one launch per net), with results bit
+ * for bit those of separate launches.  A match is a fixed cohort under azh_engine_set_game_limit, and its last games want
+ * azh_engine_set_thin_batches (below). */
 int azh_engine_run_arena(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations);
 int azh_engine_sync(azh_engine *e);
 /* change the root-visit threshold (global_visits) for the coming moves; 1 <= visits <= the

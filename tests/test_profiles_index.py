@@ -15,3 +15,16 @@ def test_every_profile_file_is_indexed_and_every_index_line_names_a_file():
     present = {f for f in os.listdir(os.path.join(ROOT, "profiles")) if f != "INDEX.md"}
     assert present - named == set(), "not in profiles/INDEX.md: %s" % sorted(present - named)
     assert named - present == set(), "indexed but missing: %s" % sorted(named - present)
+
+
+def test_committed_pmc_summaries_are_measurements_of_the_tower_source_in_the_tree():
+    """bench.py reports roofline.traffic from the committed rocprofv3 PMC summary only while that summary names the sha256 of
+    the kernel source in the tree (tools/prof_bench.sh writes it).  A tower edit without a new PMC run makes the driver's line
+    say `traffic: null`: this test says so first."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    for streams in (2, 1):
+        traffic, src = bench.measured_traffic(streams)
+        assert traffic is not None and traffic > 1e7, (streams, src)
+        assert src == bench.PMC_SUMMARY[streams]
