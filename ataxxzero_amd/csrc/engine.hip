@@ -1837,7 +1837,7 @@ static int launch_eval(azh_engine *e, azh_net *net, int dtype, const int *list, 
     }
     return azh_net_launch_sym(net, dtype, (const unsigned long long *)e->P.leaf_board, list, count, e->P.G,
                               e->P.blockers, e->d_sym_logits, e->d_sym_values, e->P.logits, e->P.values, e->stream,
-                              e->P.G * 8 <= AZH_THIN_MAX_GAMES || e->thin_mode == 1);
+                              e->thin_mode >= 0 ? e->thin_mode : (e->P.G * 8 <= AZH_THIN_MAX_GAMES ? 1 : 0));  // (8 virtual boards per leaf)
 }
 
 extern "C" int azh_engine_eval(azh_engine *e, azh_net *net, int dtype)

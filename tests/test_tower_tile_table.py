@@ -42,3 +42,20 @@ def test_table_properties():
     # wave half 1 (tiles 5-9, inner tap index = dx): tile 5 on x = 0, tile 6 on x = 6
     assert all(xy(c)[0] == 0 for c in rows[5] if c < 0x100)
     assert all(xy(c)[0] == 6 for c in rows[6] if c < 0x100)
+
+
+def test_thin_geometry_table_covers_board_zero_once_and_keeps_the_bank_rule():
+    """TILE_CELL1 (Geo2Thin: one board per workgroup): the 49 cells of board 0 — slots 21 y + x of the same LDS image — exactly
+    once over four 16-lane tiles, lane r again a slot with slot % 16 == r, empty lanes marked 0x100 | r."""
+    with open(os.path.join(ROOT, "ataxxzero_amd", "csrc", "net_kernels.hip")) as f:
+        text = f.read()
+    body = text[text.index("TILE_CELL1[4][16] = {"):]
+    body = body[:body.index("};")]
+    rows = [[int(v, 16) for v in re.findall(r"0x[0-9a-fA-F]+", line)] for line in body.splitlines()[1:] if "0x" in line]
+    assert len(rows) == 4 and all(len(r) == 16 for r in rows)
+    cells = sorted(c for r in rows for c in r if c < 0x100)
+    assert cells == sorted(21 * y + x for y in range(7) for x in range(7))
+    for r in rows:
+        for lane, c in enumerate(r):
+            assert (c & 0xFF) % 16 == lane
+            assert c < 0x100 or c == 0x100 | lane
