@@ -3,7 +3,7 @@
 // position that depends on the data just read (a PUCT level: the next node is only known once this node's children are
 // scored).  Reports, for W chains in flight over a buffer of a few GiB, the time per dependent step and the bytes per
 // second of the whole chip — i.e. what HBM3E and the fabric deliver for THIS access pattern, to put beside the 8 TB/s of
-// streaming reads.  build: hipcc -O3 --offload-arch=gfx950 random_chase.hip -o random_chase ; run: ./random_chase [GiB [reads per step: 1 | 2]]
+// streaming reads.  build: hipcc -O3 --offload-arch=gfx950 random_chase.hip -o random_chase ; run: ./random_chase [GiB [reads per step: 1 | 2 [lanes,lanes,...]]]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -74,7 +74,18 @@ int main(int argc, char **argv)
            gib, n_regions, region_records, reads);
     printf("%6s %6s %8s | %10s %12s %12s\n", "waves", "lanes", "B/lane", "us/step", "GB/s (req.)", "GB/s (64B sectors)");
     const int steps = 48;
-    for (int lanes : {42, 64}) {
+    // lanes per request: the engine's 42 (a node's children) and a full wave; `./random_chase GiB reads 4,8,16` measures
+    // other request sizes (what a level would cost if it read only a node's VISITED children: DESIGN.md section 8)
+    std::vector<int> lane_list = {42, 64};
+    if (argc > 3) {
+        lane_list.clear();
+        for (const char *p = argv[3]; *p;) {
+            lane_list.push_back(atoi(p));
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+    }
+    for (int lanes : lane_list) {
         for (int waves : {256, 1024, 2048, 4096, 8192, 16384, 32768}) {
             float best = 1e30f;
             for (int rep = 0; rep < 4; rep++) {
