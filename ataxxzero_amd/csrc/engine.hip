@@ -156,11 +156,12 @@ __device__ inline Arena arena_of(const EngineParams &P, int a, int g)
 // The 16-byte edge record.  Everything a PUCT level needs about a child sits in it: 16 B per child instead of the 24
 // of a separate (first_edge, n_edges) array — the descents of thousands of games are in flight together and their
 // level loads share the memory system (tools/tree_stamps.py: a level costs 0.93 us at 1024 games, 1.37 at 4096).
-//   x  prior (f32 bits)                      y  total score W (f32 bits)
+//   x  prior (f32 bits; >= 0, so bit 31 is free: it MARKS the child the last descent through this node chose —
+//      select_game's early request of the next level; never read by anything that decides, masked out of the documented
+//      tree, PRIOR_MASK)                     y  total score W (f32 bits)
 //   z  visits (bits 0-15) | child node (bits 16-31, ENONE = not expanded)
-//   w  the child's first edge (bits 0-22) | its edge count (bits 23-30) | finished position (bit 31); in an edge WITHOUT a
-//      child the word is free: the node's first such edge keeps 1 << 31 | index of the child the last descent chose here
-//      (select_game's early request of the next level; never read by anything else, not part of the documented tree)
+//   w  the child's first edge (bits 0-22) | its edge count (bits 23-30) | finished position (bit 31); 0 in an edge without
+//      a child (rounds 3-4 kept the descent's hint in the first such edge's word: AZH_HINT_SIGN=0)
 // visits <= 60000 and nodes <= visits + 8 (azh_engine_create), edges per game < 2^23, moves per position <= 255.
 constexpr u32 ENONE = 0xFFFFu;
 __device__ inline u32 edge_visits(const uint4 &e) { return e.z & 0xFFFFu; }
@@ -348,6 +349,14 @@ __global__ __launch_bounds__(WAVE) void k_init(EngineParams P)
 #ifndef AZH_SQRT_EARLY
 #define AZH_SQRT_EARLY 1
 #endif
+// Where a node keeps "the child the last descent chose here" (select_game's early request): 1 = the SIGN BIT of that child's
+// prior (priors are >= 0, so the bit is free in every edge: found with one ballot, and present in nodes whose children have
+// all been visited — the tree's upper levels); 0 = the spare word of the node's first unvisited edge (rounds 3-4: two ballots,
+// a find-first-set and a lane read to find, and nothing to find in a fully visited node).
+#ifndef AZH_HINT_SIGN
+#define AZH_HINT_SIGN 1
+#endif
+constexpr u32 PRIOR_MASK = 0x7FFFFFFFu;  // the prior proper (AZH_HINT_SIGN: bit 31 marks the remembered child)
 __device__ inline float puct_sqrt(float x)
 {
 #if AZH_FAST_SCORE
@@ -358,6 +367,7 @@ __device__ inline float puct_sqrt(float x)
 }
 __device__ inline float puct_score(float prior, float W, u32 n, float sq, float c_puct)
 {
+    prior = __builtin_fabsf(prior);  // (the sign bit may carry the descent's mark: a source modifier, no instruction)
 #if AZH_FAST_SCORE
     const float q = n ? W * __builtin_amdgcn_rcpf((float)n) : 0.0f;
     const float u = (sq * __builtin_amdgcn_rcpf(1.0f + (float)n)) * (c_puct * prior);
@@ -441,8 +451,8 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             }
         };
         // Early request of the next level (never changes what is selected): a node remembers which child the last descent
-        // through it chose, in the `w` word of its first UNVISITED edge (an edge without a child has no use for the word;
-        // 1 << 31 | index; an expansion that takes that edge simply overwrites it).  When a node's records arrive, the
+        // through it chose — the sign bit of that child's prior (priors are >= 0; one ballot finds it, and every node has
+        // room for it, the fully visited nodes of the upper levels included).  When a node's records arrive, the
         // remembered child's own records — its range is in this node's records — are requested at once and the scores are
         // computed while they are in flight; if the scores pick that child, the next level starts with its records
         // already on the way: a level then costs max(memory latency, its instructions) instead of their sum.
@@ -476,9 +486,33 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             const bool two = M > WAVE;
             const bool live0 = lane < M, live1 = two && lane + WAVE < M;
             // the remembered child, requested before anything is scored
+            int u0 = -1, pv = -1, pred = -1;
+            auto request_child = [&](int idx) {
+                u32 pz, pk;
+                if (idx < WAVE) {
+                    pz = (u32)read_lane((int)e0.z, idx);
+                    pk = (u32)read_lane((int)e0.w, idx);
+                } else {
+                    pz = (u32)read_lane((int)e1.z, idx - WAVE);
+                    pk = (u32)read_lane((int)e1.w, idx - WAVE);
+                }
+                if ((pz >> 16) != ENONE && !kid_finished(pk) && kid_count(pk) > 0 && kid_count(pk) <= 2 * WAVE) {
+                    load_children(pk, p0, p1);
+                    pred = idx;
+                }
+            };
+#if AZH_HINT_SIGN
+            {
+                const u64 mk0 = __ballot(live0 && (int)e0.x < 0);
+                const u64 mk1 = two ? __ballot(live1 && (int)e1.x < 0) : 0ull;
+                if (mk0 | mk1) {
+                    pv = mk0 ? __ffsll((long long)mk0) - 1 : WAVE + __ffsll((long long)mk1) - 1;
+                    request_child(pv);
+                }
+            }
+#else
             const u64 unv0 = __ballot(live0 && edge_child(e0) == ENONE);
             const u64 unv1 = two ? __ballot(live1 && edge_child(e1) == ENONE) : 0ull;
-            int u0 = -1, pv = -1, pred = -1;
             if (unv0 | unv1) {
                 u32 hw;
                 if (unv0) {
@@ -491,20 +525,10 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 }
                 if ((hw >> 31) && (int)(hw & 0xFFu) < M) {
                     pv = (int)(hw & 0xFFu);
-                    u32 pz, pk;
-                    if (pv < WAVE) {
-                        pz = (u32)read_lane((int)e0.z, pv);
-                        pk = (u32)read_lane((int)e0.w, pv);
-                    } else {
-                        pz = (u32)read_lane((int)e1.z, pv - WAVE);
-                        pk = (u32)read_lane((int)e1.w, pv - WAVE);
-                    }
-                    if ((pz >> 16) != ENONE && !kid_finished(pk) && kid_count(pk) > 0 && kid_count(pk) <= 2 * WAVE) {
-                        load_children(pk, p0, p1);
-                        pred = pv;
-                    }
+                    request_child(pv);
                 }
             }
+#endif
             const u32 n0 = edge_visits(e0), n1 = edge_visits(e1);
             float sq1;
             if (AZH_SQRT_EARLY && have_n)
@@ -555,8 +579,21 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 return false;
             }
             // remember the choice (stored only when it changes)
+#if AZH_HINT_SIGN
+            if (bj != pv) {
+                // the mark moves: the lane that holds the newly chosen edge sets its prior's sign bit, the lane that holds
+                // the edge chosen last time clears it (one store instruction, two lanes)
+                const bool set_me = lane == (bj & 63), clr_me = pv >= 0 && lane == (pv & 63);
+                if (set_me || clr_me) {
+                    const int idx = set_me ? bj : pv;
+                    const u32 xw = idx >= WAVE ? e1.x : e0.x;
+                    reinterpret_cast<u32 *>(&A.ed[first + (u32)idx])[0] = set_me ? (xw | ~PRIOR_MASK) : (xw & PRIOR_MASK);
+                }
+            }
+#else
             if (u0 >= 0 && bj != pv && lane == 0)
                 reinterpret_cast<u32 *>(&A.ed[first + (u32)u0])[3] = 0x80000000u | (u32)bj;
+#endif
             node = child;
             kid = wsel;
             n_node = (zsel & 0xFFFFu) - 1u;
@@ -701,7 +738,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                 const uint4 kinfo = A.ni[known];
                 const u32 nf = (u32)s.n_edges;
                 for (int j = lane; j < M2; j += WAVE) {
-                    A.ed[nf + j] = fresh_edge(A.ed[kinfo.x + j].x);
+                    A.ed[nf + j] = fresh_edge(A.ed[kinfo.x + j].x & PRIOR_MASK);  // (without the other node's mark)
                     A.em[nf + j] = s_moves[j];
                 }
                 s.n_edges += M2;
@@ -2138,6 +2175,7 @@ extern "C" int azh_engine_tree(azh_engine *e, int game, uint64_t *boards, uint32
         for (int j = 0; j < s.n_edges; j++) {  // device record (prior, W, visits | child << 16, child's range) -> documented row
             uint32_t *r = edges + 4 * (size_t)j;
             const uint32_t w = r[1], z = r[2];
+            r[0] &= PRIOR_MASK;  // (the sign bit is the descent's mark, not part of the tree)
             r[1] = z & 0xFFFFu;
             r[2] = w;
             r[3] = (z >> 16) == 0xFFFFu ? 0xFFFFFFFFu : (z >> 16);
