@@ -486,7 +486,10 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             const bool two = M > WAVE;
             const bool live0 = lane < M, live1 = two && lane + WAVE < M;
             // the remembered child, requested before anything is scored
-            int u0 = -1, pv = -1, pred = -1;
+            int pv = -1, pred = -1;
+#if !AZH_HINT_SIGN
+            int u0 = -1;
+#endif
             auto request_child = [&](int idx) {
                 u32 pz, pk;
                 if (idx < WAVE) {
