@@ -533,6 +533,36 @@ def test_two_half_batches_in_flight_match_their_oracles_at_bench_size():
     sp.close()
 
 
+def test_thin_batch_switch_in_the_device_loop():
+    """azh_engine_set_thin_batches in the middle of a run (what arena.Match and the generator do for their last games): with
+    the f32 tower, which has one kernel, the search stays the oracle's bit for bit whatever the mode; with bf16 the one-board-
+    per-workgroup kernel takes over and the search stays a valid search (counters consistent, written games replay)."""
+    conv, bn = model.random_init(2, 128, seed=7)
+    net = link.Net(conv, bn)
+    oe, ge = make_pair(games=600, visits=24, max_plies=120, seed=13, select_budget=8)   # 600 slots: the 3-board tower by default
+    for mode in (-1, 1, 0):
+        ge.set_thin_batches(mode)
+        ge.run(net, 60, link.DTYPE_F32)
+        _oracle_follow(oe, net, oe.cfg.blockers, 60)
+        ge.sync()
+        compare_all(oe, ge, range(0, 600, 7))
+    with pytest.raises(link.AzhError):
+        ge.set_thin_batches(2)
+    sp = selfplay.SelfPlay(conv, bn, games=600, visits=24, dtype="bf16", seed=5, max_plies=120)
+    lines = []
+    for mode in (-1, 1, 1, 0, 1):
+        sp.set_thin_batches(mode)
+        sp.run(150)
+        lines += sp.drain()
+    st = sp.stats()
+    assert st["games"] == len(lines) > 20 and st["edge_overflow"] == 0 and st["ring_overflow"] == 0
+    assert st["nn_evals"] <= st["steps"] + st["plies"] + st["games"] + st["dropped"] + 600
+    for line in lines[:40]:
+        entry = json.loads(line)
+        assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
+    sp.close()
+
+
 def test_uid_ordered_emission_is_an_unbiased_prefix():
     """azh_engine_set_emit_order(1): games come out in the order they were STARTED.  What has been handed out at any
     moment is exactly the finished games among the uids below the smallest uid still in play — short and long games

@@ -28,3 +28,21 @@ def test_committed_pmc_summaries_are_measurements_of_the_tower_source_in_the_tre
         traffic, src = bench.measured_traffic(streams)
         assert traffic is not None and traffic > 1e7, (streams, src)
         assert src == bench.PMC_SUMMARY[streams]
+
+
+def test_a_pmc_summary_of_another_kernel_source_is_not_reported(tmp_path, monkeypatch):
+    """roofline.traffic goes null — and says why — when the committed summary was measured with another tower source."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    good = open(os.path.join(ROOT, bench.PMC_SUMMARY[2])).read()
+    stale = tmp_path / "stale.txt"
+    stale.write_text(re.sub(r"sha256: [0-9a-f]{64}", "sha256: " + "0" * 64, good))
+    unnamed = tmp_path / "unnamed.txt"
+    unnamed.write_text(re.sub(r"kernel source sha256: [0-9a-f]{64}[^\n]*\n", "", good))
+    for path in (stale, unnamed):
+        monkeypatch.setitem(bench.PMC_SUMMARY, 2, str(path))
+        traffic, why = bench.measured_traffic(2)
+        assert traffic is None and "stale" in why
+    monkeypatch.setitem(bench.PMC_SUMMARY, 2, str(tmp_path / "missing.txt"))
+    assert bench.measured_traffic(2) == (None, None)
