@@ -490,6 +490,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
 #if !AZH_HINT_SIGN
             int u0 = -1;
 #endif
+#if !AZH_HINT_SIGN
             auto request_child = [&](int idx) {
                 u32 pz, pk;
                 if (idx < WAVE) {
@@ -504,13 +505,20 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
                     pred = idx;
                 }
             };
+#endif
 #if AZH_HINT_SIGN
             {
-                const u64 mk0 = __ballot(live0 && (int)e0.x < 0);
-                const u64 mk1 = two ? __ballot(live1 && (int)e1.x < 0) : 0ull;
+                // (a mark is only ever set on an edge whose child exists, is not a finished position and has 1 .. 128 moves
+                // — below — and none of that changes while the edge lives: nothing to check here, one lane read)
+                // (no live mask: a lane past the node's last edge holds a copy of that last edge, so the FIRST set bit is
+                // always the marked edge itself — and a bare compare writes the lane mask without a detour through a register)
+                const u64 mk0 = __ballot((int)e0.x < 0);
+                const u64 mk1 = two ? __ballot((int)e1.x < 0) : 0ull;
                 if (mk0 | mk1) {
                     pv = mk0 ? __ffsll((long long)mk0) - 1 : WAVE + __ffsll((long long)mk1) - 1;
-                    request_child(pv);
+                    const u32 pk = pv < WAVE ? (u32)read_lane((int)e0.w, pv) : (u32)read_lane((int)e1.w, pv - WAVE);
+                    load_children(pk, p0, p1);
+                    pred = pv;
                 }
             }
 #else
@@ -586,7 +594,8 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             if (bj != pv) {
                 // the mark moves: the lane that holds the newly chosen edge sets its prior's sign bit, the lane that holds
                 // the edge chosen last time clears it (one store instruction, two lanes)
-                const bool set_me = lane == (bj & 63), clr_me = pv >= 0 && lane == (pv & 63);
+                const bool markable = !kid_finished(wsel) && kid_count(wsel) > 0 && kid_count(wsel) <= 2 * WAVE;
+                const bool set_me = markable && lane == (bj & 63), clr_me = pv >= 0 && lane == (pv & 63);
                 if (set_me || clr_me) {
                     const int idx = set_me ? bj : pv;
                     const u32 xw = idx >= WAVE ? e1.x : e0.x;
