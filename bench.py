@@ -387,6 +387,7 @@ def main():
     ap.add_argument("--no-target-leg", action="store_true", help="skip the 16384-game leg reported beside the headline")
     ap.add_argument("--legs", default="all",
                     help="comma-separated legs to measure beside the headline (default all): one_batch, target_10k_games, "
+                         "target_10k_games_two_half_batches, "
                          "with_eval_cache, target_10k_games_with_eval_cache, with_f16, config1_random_play, config2, config4, "
                          "config5_arena")
     ap.add_argument("--other-configs-games", type=int, default=0,
@@ -544,6 +545,10 @@ def main():
                 "achieved": ob["tree_roofline_frac"] * HBM_PEAK_GBS, "source": alone}
         if want("target_10k_games"):
             out["target_10k_games"] = target_leg(conv, bn, args)
+        if want("target_10k_games_two_half_batches") and args.streams != 1:
+            # the same 16384 games as two half-batches of 8192 in flight (+1.8 % with round 5's tree kernels; the one-batch leg
+            # above keeps the launches alone on the chip: its fractions are the kernels' own)
+            out["target_10k_games_two_half_batches"] = target_leg(conv, bn, args, streams=args.streams)
         if not args.eval_cache:
             # the same workload with AZH_FLAG_EVAL_CACHE (the generator CLI's default): MCTS steps/s and games/s rise,
             # net evaluations/s do not (the headline keeps the C++ generator's rule: every new node goes to the net)
