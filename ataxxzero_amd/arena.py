@@ -68,14 +68,17 @@ class Match:
         self.games = games
         self.opening_depth = opening_depth
         self.openings = None
+        self.opening_boards = None   # (pairs, 2) u64: the position after each pairing's opening
         self.limit = None        # set_game_limit: the size of the match
         self.finished = 0        # games handed out so far
+        self.thin = False        # the tower runs one board per workgroup (the match's last games)
         if opening_depth > 0:
             # every pairing gets its own random opening, played both ways (uai_ringmaster.py:242-246): slots 2k and 2k + 1
             # start from the same position.  Only the FIRST game of a slot starts from it (uid < games): a match from
             # openings is a cohort of at most `games` games.
             import numpy as np
             boards, self.openings = random_openings(games // 2, opening_depth, seed)
+            self.opening_boards = boards
             self.engine.set_positions(np.repeat(boards, 2, axis=0), np.full(games, opening_depth, dtype=np.int32))
 
     def set_game_limit(self, games):
@@ -84,6 +87,18 @@ class Match:
         last, longest games run at the latency of a nearly empty batch (azh_engine_set_game_limit)."""
         self.engine.set_game_limit(games)
         self.limit = games
+        self._pick_tower()
+
+    def _pick_tower(self):
+        """The match's last games — at most link.THIN_MAX_GAMES left of a match that started with more in flight — are a
+        handful of leaves per iteration, whose cost is one workgroup's time for the whole net: the tower then runs one board
+        per workgroup (azh_engine_set_thin_batches).  Decided by the count of games handed out, at a drain or when the limit
+        moves: the same point in every run of the same match (the two 16-bit kernels differ in the last bits).  A limit that
+        is RAISED past that point (uai_ringmaster.py keeps a branch for callers that do) brings the throughput kernel back."""
+        thin = self.limit is not None and self.limit - self.finished <= link.THIN_MAX_GAMES < self.games
+        if thin != self.thin:
+            self.engine.set_thin_batches(1 if thin else -1)
+            self.thin = thin
 
     def run(self, iterations):
         self.engine.run_arena(self.net_a, self.net_b, iterations, self.dtype)
@@ -107,12 +122,22 @@ class Match:
             out.append({"moves": e["moves"], "result": e["result"], "white": white, "uid": e["uid"],
                         "final_score": replay_final_score(e), "boards": e["boards"], "opening": opening})
         self.finished += len(out)
-        # the match's last games: a handful of leaves per iteration, whose cost is one workgroup's time for the whole net —
-        # from here on the tower runs one board per workgroup (azh_engine_set_thin_batches).  Decided at a drain, by the
-        # count of games handed out: the same point in every run of the same match.
-        if self.limit is not None and self.limit - self.finished <= link.THIN_MAX_GAMES < self.games:
-            self.engine.set_thin_batches(1)
+        self._pick_tower()
         return out
+
+    def lost_games(self):
+        """Why the match can no longer be completed, or None.  A cohort under a game limit ends when every one of its games
+        has been handed out; a record that did not fit the device's ring (the host did not drain for far too long) never
+        comes, and a loop `while handed_out < cohort` would then enqueue search for an idle engine for ever.  Call right
+        after fetch(): the engine's streams are idle there (the call costs one small kernel and waits for nothing), and
+        every game the counters know of has been taken off the device — so after the drain that follows, a game the engine
+        has ended and the host has not seen is a lost one."""
+        st = self.engine.stats()
+        if st["ring_overflow"] > 0:
+            return "%d finished games did not fit the device's record ring and are lost" % st["ring_overflow"]
+        if self.limit is not None and st["games"] + st["dropped"] >= self.limit:
+            return "the engine has ended all %d games of the match" % self.limit   # (a reason only if some were not handed out)
+        return None
 
     def close(self):
         self.engine.close()

@@ -592,15 +592,16 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
             // remember the choice (stored only when it changes)
 #if AZH_HINT_SIGN
             if (bj != pv) {
-                // the mark moves: the lane that holds the newly chosen edge sets its prior's sign bit, the lane that holds
-                // the edge chosen last time clears it (one store instruction, two lanes)
+                // the mark moves: the lane that holds the edge chosen last time clears its prior's sign bit, the lane that
+                // holds the newly chosen edge sets it.  Two predicated stores: bj and pv may be 64 apart, i.e. the two
+                // edges of ONE lane — as one store with a per-lane choice of the edge that lane dropped its clear, and the
+                // node kept two marks for good (found by the round-5 review; tests/test_gpu_engine.py reads the raw marks).
+                // The mark moves in about one level of a hundred: the second store is not on the level's usual path.
                 const bool markable = !kid_finished(wsel) && kid_count(wsel) > 0 && kid_count(wsel) <= 2 * WAVE;
-                const bool set_me = markable && lane == (bj & 63), clr_me = pv >= 0 && lane == (pv & 63);
-                if (set_me || clr_me) {
-                    const int idx = set_me ? bj : pv;
-                    const u32 xw = idx >= WAVE ? e1.x : e0.x;
-                    reinterpret_cast<u32 *>(&A.ed[first + (u32)idx])[0] = set_me ? (xw | ~PRIOR_MASK) : (xw & PRIOR_MASK);
-                }
+                if (pv >= 0 && lane == (pv & 63))
+                    reinterpret_cast<u32 *>(&A.ed[first + (u32)pv])[0] = (pv >= WAVE ? e1.x : e0.x) & PRIOR_MASK;
+                if (markable && lane == (bj & 63))
+                    reinterpret_cast<u32 *>(&A.ed[first + (u32)bj])[0] = (bj >= WAVE ? e1.x : e0.x) | ~PRIOR_MASK;
             }
 #else
             if (u0 >= 0 && bj != pv && lane == 0)
@@ -959,8 +960,9 @@ __device__ inline void backup_game(const EngineParams &P, int g, azh_game_state 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = lane + 64 * k;
-            if (k < rounds && j < M)
-                reinterpret_cast<u32 *>(&A.ed[first + j])[0] = f2u(pr[k]);
+            if (k < rounds && j < M)  // (stored without a sign: bit 31 is the descent's mark.  Priors are >= 0 and never NaN —
+                                      // det_expf is 0 for a NaN argument — so the mask changes nothing: belt and braces)
+                reinterpret_cast<u32 *>(&A.ed[first + j])[0] = f2u(pr[k]) & PRIOR_MASK;
         }
     }
 
@@ -1641,6 +1643,11 @@ struct azh_engine {
     std::vector<int> close_of;       // per sample: index of the event that closes its tree phase
     bool close_pending = false;      // the last sample's tree phase is closed at the start of the next iteration
     int *h_count = nullptr;  // pinned
+    // pinned staging of azh_engine_fetch: the ring's head and its records are copied here (a copy into pageable memory is
+    // staged by the runtime through buffers of its own and may serialise with other streams' copies), then into `staged`
+    u64 *h_head = nullptr;
+    u32 *h_stage = nullptr;
+    size_t h_stage_words = 0;
     bool selected = false;
     bool arena_lists = false;  // run_arena: one leaf list per net
     bool stamp_next = false;   // azh_engine_tree_stamps: the next fused tree launch of the loop is the stamped instantiation
@@ -1749,7 +1756,8 @@ extern "C" int azh_engine_create(const azh_config *cfg, azh_engine **out)
         hipStreamCreateWithPriority(&e->stream2, hipStreamDefault, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_sel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_adv, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void **)&e->h_count, sizeof(int)) != hipSuccess) {
+        hipHostMalloc((void **)&e->h_count, sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_head, sizeof(u64)) != hipSuccess) {
         azh_engine_destroy(e);
         return azh_fail(-4, "azh_engine_create: stream / pinned allocation failed");
     }
@@ -1782,6 +1790,10 @@ extern "C" void azh_engine_destroy(azh_engine *e)
         (void)hipFree(e->d_sym_values);
     if (e->h_count)
         (void)hipHostFree(e->h_count);
+    if (e->h_head)
+        (void)hipHostFree(e->h_head);
+    if (e->h_stage)
+        (void)hipHostFree(e->h_stage);
     if (e->ev_sel)
         (void)hipEventDestroy(e->ev_sel);
     if (e->ev_adv)
@@ -2197,6 +2209,22 @@ extern "C" int azh_engine_tree(azh_engine *e, int game, uint64_t *boards, uint32
     return 0;
 }
 
+// Diagnostic: the game's edge records as they lie in HBM (the 16-byte device record described at the top of this file,
+// the descent's mark in bit 31 of word 0 included) — what azh_engine_tree turns into the documented rows.  For the test
+// of the mark's invariants: at most one marked edge per node, and only on an edge whose child exists, is unfinished and
+// has 1 .. 128 moves.
+extern "C" int azh_engine_tree_raw(azh_engine *e, int game, uint32_t *edges)
+{
+    if (!e || !edges || game < 0 || game >= e->P.G)
+        return azh_fail(-1, "azh_engine_tree_raw: bad argument");
+    azh_game_state s;
+    if (azh_engine_game_state(e, game, &s))
+        return -1;
+    const size_t slot = (size_t)s.arena * e->P.G + game;
+    AZH_HIP(hipMemcpy(edges, e->P.edge + slot * e->P.edge_cap, (size_t)s.n_edges * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int azh_engine_stats(azh_engine *e, uint64_t *out)
 {
     if (!e || !out)
@@ -2259,9 +2287,9 @@ static int fetch_records(azh_engine *e)
     AZH_HIP(hipStreamSynchronize(e->stream));
     AZH_HIP(hipStreamSynchronize(e->stream2));  // (idle by now: the last tree launch of a run waits for the last re-roots)
     e->unfetched_work = false;
-    u64 head = 0;
-    AZH_HIP(hipMemcpyAsync(&head, e->P.ring_head, 8, hipMemcpyDeviceToHost, e->stream));
+    AZH_HIP(hipMemcpyAsync(e->h_head, e->P.ring_head, 8, hipMemcpyDeviceToHost, e->stream));
     AZH_HIP(hipStreamSynchronize(e->stream));
+    u64 head = *e->h_head;
     if (head > e->P.ring_cap_words) {
         // A record or a drop marker did not fit (AZH_STAT_RING_OVERFLOW counts them): its uid will never come, and
         // uid order would wait for it for ever.  From here on the order is given up instead of the games: what is
@@ -2270,13 +2298,38 @@ static int fetch_records(azh_engine *e)
         e->order_broken = true;
     }
     if (head > 0) {
-        const size_t at = e->staged.size();
-        e->staged.resize(at + (size_t)head);
-        AZH_HIP(hipMemcpyAsync(e->staged.data() + at, e->P.ring, (size_t)head * 4, hipMemcpyDeviceToHost, e->stream));
+        if ((size_t)head > e->h_stage_words) {
+            // (grows to the largest fetch seen, in powers of two from 4 MiB: a round's records, not the ring's capacity)
+            size_t want = (size_t)1 << 20;
+            while (want < (size_t)head)
+                want <<= 1;
+            if (e->h_stage)
+                (void)hipHostFree(e->h_stage);
+            e->h_stage = nullptr;
+            e->h_stage_words = 0;
+            AZH_HIP(hipHostMalloc((void **)&e->h_stage, want * 4));
+            e->h_stage_words = want;
+        }
+        AZH_HIP(hipMemcpyAsync(e->h_stage, e->P.ring, (size_t)head * 4, hipMemcpyDeviceToHost, e->stream));
         AZH_HIP(hipMemsetAsync(e->P.ring, 0, (size_t)head * 4, e->stream));
         AZH_HIP(hipMemsetAsync(e->P.ring_head, 0, 8, e->stream));
         AZH_HIP(hipStreamSynchronize(e->stream));
+        e->staged.insert(e->staged.end(), e->h_stage, e->h_stage + (size_t)head);
     }
+    return 0;
+}
+
+// 1 while work enqueued on the engine is still in flight, 0 when it is idle: a query, never a wait.  (The main stream is
+// the one asked: the last tree launch of a run waits for the last re-roots of the side stream, so an idle main stream
+// means an idle engine.)
+extern "C" int azh_engine_query(azh_engine *e)
+{
+    if (!e)
+        return azh_fail(-1, "azh_engine_query: null engine");
+    const hipError_t rc = hipStreamQuery(e->stream);
+    if (rc == hipErrorNotReady)
+        return 1;
+    AZH_HIP(rc);
     return 0;
 }
 

@@ -100,11 +100,13 @@ SIGNATURES = {
     "azh_engine_set_thin_batches": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_game_state": (ctypes.c_int, [_vp, ctypes.c_int, _P(GameState)]),
     "azh_engine_tree": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "azh_engine_tree_raw": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "azh_engine_stats": (ctypes.c_int, [_vp, _vp]),
     "azh_engine_tree_stamps": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
     "azh_engine_timing_reset": (ctypes.c_int, [_vp, ctypes.c_int]),
     "azh_engine_timing": (ctypes.c_int, [_vp, _P(Timing)]),
     "azh_engine_fetch": (ctypes.c_int, [_vp]),
+    "azh_engine_query": (ctypes.c_int, [_vp]),
     "azh_engine_implicit_fetches": (ctypes.c_longlong, [_vp]),
     "azh_engine_drain_json": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _P(ctypes.c_int64), _P(_i32)]),
     "azh_format_record_json": (ctypes.c_int, [_vp, ctypes.c_int64, _i32, _vp, ctypes.c_int64, _P(ctypes.c_int64)]),
@@ -414,6 +416,13 @@ class Engine:
         check(load().azh_engine_tree(self.h, g, _ptr(boards), _ptr(info), _ptr(edges), _ptr(moves)))
         return boards, info, edges, moves
 
+    def tree_raw(self, g):
+        """The game's edges as the 16-byte device records (prior bits with the descent's mark in bit 31, score bits,
+        visits | child << 16, the child's edge range): diagnostic, azh_engine_tree_raw."""
+        edges = np.zeros((self.game_state(g).n_edges, 4), dtype=np.uint32)
+        check(load().azh_engine_tree_raw(self.h, g, _ptr(edges)))
+        return edges
+
     def stats(self):
         out = np.zeros(STAT_COUNT, dtype=np.uint64)
         check(load().azh_engine_stats(self.h, _ptr(out)))
@@ -439,6 +448,13 @@ class Engine:
         """Wait for the work enqueued so far and take its finished games off the device; the next drain_json formats
         them without touching the GPU (so the next run can be enqueued in between)."""
         check(load().azh_engine_fetch(self.h))
+
+    def busy(self):
+        """True while work enqueued on this engine's streams is still in flight (a query: never waits)."""
+        rc = load().azh_engine_query(self.h)
+        if rc < 0:
+            check(rc)
+        return rc == 1
 
     def implicit_fetches(self):
         """Times a drain had to fetch by itself (= waited for the device); 0 in a loop that fetches before it drains."""

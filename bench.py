@@ -236,27 +236,50 @@ def target_leg(conv, bn, args, games=16384, steps=8, warmup=1, flags=0, dtype=No
         sp.close()
 
 
-def config5_leg(games=1000, visits=100, dtype="f16", seed=None):
+def config5_leg(games=1000, visits=100, dtype="f16", seed=None, net_seeds=(1, 2)):
     """BASELINE configs[4] (uai_ringmaster.py with two uai_interface.py engines, :75-160,221-265) through this repo's batched
-    arena: a FIXED cohort of `games` games — every pairing both ways — between two random-init 12x128 nets (seeds 1 and 2),
+    arena: a FIXED cohort of `games` games — every pairing both ways — between two random-init 12x128 nets (`net_seeds`),
     `visits` MCTS steps per move from a fresh tree, played to completion as uai_ringmaster.py's drop-in plays it (50 search
     iterations per round trip, finished games drained and scored; thin batches — one board per workgroup — once at most 512
-    games of the match are left).  The wall time is the longest game of the cohort at the
-    latency of a thinning batch; the rates are whole-cohort figures."""
+    games of the match are left).  What the figures mean: `wall_s` is the longest game of the cohort at the latency of a
+    thinning batch — with one game cut at 400 plies most of it prices a near-empty batch — so the leg also says when 99 %
+    of the games were over (`wall_s_until_99pct_games`, `iterations_until_99pct`), the rates while the batch was still a batch
+    (`..._while_ge512_live`: up to the fetch after which at most 512 games were left = the switch to thin batches), and one
+    tower launch's own rate from HIP events (`per_launch_frac`, every 8th launch; over the whole match and over that
+    first phase)."""
     from ataxxzero_amd import arena, model, selfplay
     ROUND = 50   # search iterations per host round trip (uai_ringmaster.py's drop-in uses the same)
-    wa, wb = model.random_init(12, 128, seed=1), model.random_init(12, 128, seed=2)
+    wa, wb = model.random_init(12, 128, seed=net_seeds[0]), model.random_init(12, 128, seed=net_seeds[1])
     m = arena.Match(wa, wb, visits, games=games, dtype=dtype, seed=selfplay.DEFAULT_SEED if seed is None else seed)
+    flops = model.flops_per_eval(12, 128)
+    peak = MFMA_PEAK_TFLOPS[dtype]
+
+    def launch_rate(d, tm):   # one tower launch's own rate: evaluations per launch x FLOPs / its average duration
+        it = max(tm["iterations"], 1)
+        ms = tm["net_ms"] / it
+        evals = d["nn_evals"] / float(max(d["iterations"], 1))
+        return {"evals_per_launch": evals, "tower_ms_per_launch": ms,
+                "per_launch_tflops": evals * flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+
     try:
         m.set_game_limit(games)   # a slot whose cohort game is over goes idle (uai_ringmaster.py does the same)
         m.run(5)            # first launches (weight packing, kernel load) outside the region
         m.engine.sync()
         st0 = m.engine.stats()
+        m.engine.timing_reset(TIMING_STRIDE)
         t0 = time.perf_counter()
         done, wins, annulled, plies, rounds = 0, {"a": 0.0, "b": 0.0}, 0, 0, 1
+        p99 = thick = None          # (wall s, iterations) when 99 % of the games were over; the phase with >= 512 games live
+        lost = None
         m.run(ROUND)
         while done < games:
             m.fetch()
+            # between the fetch and the next run the engine is idle: counters and event timings cost no waiting here
+            if games > 512 and thick is None and games - done <= 512:
+                st, tm = m.engine.stats(), m.engine.timing()
+                thick = (time.perf_counter() - t0, ROUND * rounds, {k: st[k] - st0[k] for k in st}, tm)
+            if rounds % 16 == 0:
+                lost = m.lost_games()
             m.run(ROUND)    # the next iterations run while the finished games are parsed and scored
             rounds += 1
             for g in m.drain():
@@ -272,22 +295,46 @@ def config5_leg(games=1000, visits=100, dtype="f16", seed=None):
                     wins["a"] += 0.5
                     wins["b"] += 0.5
                     annulled += 1
+            if p99 is None and done >= 0.99 * games:
+                p99 = (time.perf_counter() - t0, ROUND * (rounds - 1))   # (the games of the iterations fetched this round)
+            if lost is not None and done < games:
+                raise RuntimeError("config5 leg: %s, but only %d of %d were handed out" % (lost, done, games))
         m.engine.sync()
         dt = time.perf_counter() - t0
         st1 = m.engine.stats()
+        tm1 = m.engine.timing()
         d = {k: st1[k] - st0[k] for k in st1}
-        flops = model.flops_per_eval(12, 128)
+        d["iterations"] = ROUND * rounds
         tf = d["nn_evals"] * flops / dt / 1e12
-        return {"workload": "uai_ringmaster.py: %d-game match (fixed cohort, every pairing both ways) of two random-init 12x128 "
-                            "nets (seeds 1, 2), %d visits/move, %s, all games in flight from the start" % (games, visits, dtype),
-                "games": done, "wall_s": dt, "games_per_s": done / dt, "mcts_steps_per_s": d["steps"] / dt,
-                "nn_evals_per_s": d["nn_evals"] / dt, "plies_per_s": d["plies"] / dt, "mean_plies": plies / float(max(done, 1)),
-                "search_iterations": ROUND * rounds, "ms_per_iteration": 1e3 * dt / (ROUND * rounds),
-                "tower_tflops": tf, "tower_frac_of_peak": tf / MFMA_PEAK_TFLOPS[dtype],
-                "two_nets_in_one_launch": os.environ.get("AZH_ARENA_PAIR", "1") != "0",
-                "score": "%s - %s (annulled: %d)" % (wins["a"], wins["b"], annulled),
-                "reference": "uai_ringmaster.py:75-160,221-265 with two `uai_interface.py --visits %d` subprocesses "
-                             "(engine.py's Python MCTS, about 1.5 k steps/s by its author's constant; not runnable here: TensorFlow-1)" % visits}
+        whole = launch_rate(d, tm1)
+        out = {"workload": "uai_ringmaster.py: %d-game match (fixed cohort, every pairing both ways) of two random-init 12x128 "
+                           "nets (seeds %d, %d), %d visits/move, %s, all games in flight from the start"
+                           % (games, net_seeds[0], net_seeds[1], visits, dtype),
+               "net_seeds": list(net_seeds),
+               "games": done, "wall_s": dt, "games_per_s": done / dt, "mcts_steps_per_s": d["steps"] / dt,
+               "nn_evals_per_s": d["nn_evals"] / dt, "plies_per_s": d["plies"] / dt, "mean_plies": plies / float(max(done, 1)),
+               "search_iterations": ROUND * rounds, "ms_per_iteration": 1e3 * dt / (ROUND * rounds),
+               "tower_tflops": tf, "tower_frac_of_peak": tf / peak,
+               "per_launch_tflops": whole["per_launch_tflops"], "per_launch_frac": whole["per_launch_tflops"] / peak,
+               "evals_per_launch": whole["evals_per_launch"], "tower_ms_per_launch": whole["tower_ms_per_launch"],
+               "wall_s_until_99pct_games": p99[0] if p99 else None, "iterations_until_99pct": p99[1] if p99 else None,
+               "two_nets_in_one_launch": os.environ.get("AZH_ARENA_PAIR", "1") != "0",
+               "score": "%s - %s (annulled: %d)" % (wins["a"], wins["b"], annulled),
+               "reference": "uai_ringmaster.py:75-160,221-265 with two `uai_interface.py --visits %d` subprocesses "
+                            "(engine.py's Python MCTS, about 1.5 k steps/s by its author's constant; not runnable here: TensorFlow-1)" % visits}
+        if thick is not None:
+            t_a, it_a, d_a, tm_a = thick
+            d_a["iterations"] = it_a
+            a = launch_rate(d_a, tm_a)
+            tf_a = d_a["nn_evals"] * flops / t_a / 1e12
+            out.update({"wall_s_while_ge512_live": t_a, "iterations_while_ge512_live": it_a,
+                        "steps_per_s_while_ge512_live": d_a["steps"] / t_a, "nn_evals_per_s_while_ge512_live": d_a["nn_evals"] / t_a,
+                        "ms_per_iteration_while_ge512_live": 1e3 * t_a / it_a,
+                        "tower_frac_of_peak_while_ge512_live": tf_a / peak,
+                        "per_launch_frac_while_ge512_live": a["per_launch_tflops"] / peak,
+                        "evals_per_launch_while_ge512_live": a["evals_per_launch"],
+                        "tower_ms_per_launch_while_ge512_live": a["tower_ms_per_launch"]})
+        return out
     finally:
         m.close()
 

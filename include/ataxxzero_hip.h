@@ -257,6 +257,11 @@ int azh_engine_game_state(azh_engine *e, int game, azh_game_state *out);
  * [n_edges][4] u32 (prior bits, visits, total score bits, child), moves [n_edges] */
 int azh_engine_tree(azh_engine *e, int game, uint64_t *boards, uint32_t *info, uint32_t *edges,
                     uint16_t *moves);
+/* Diagnostic: the same edges as the 16-byte records the tree kernels read — edges [n_edges][4] u32 = prior bits (bit 31:
+ * the mark of the child the last descent through the node chose — the early request of the next level, never part of a
+ * decision), total score bits, visits | child << 16 (0xFFFF: none), the child's edge range (first | count << 23 |
+ * finished << 31).  tests/test_gpu_engine.py checks the mark's invariants on it. */
+int azh_engine_tree_raw(azh_engine *e, int game, uint32_t *edges);
 int azh_engine_stats(azh_engine *e, uint64_t *out /* [AZH_STAT_COUNT] */);
 /* enable = 0: off; n > 0: bracket every n-th iteration of the device loop with events (tower start / tower end /
  * next tower start); at most 8192 samples are kept */
@@ -284,6 +289,8 @@ int azh_engine_drain_json(azh_engine *e, char *buf, int64_t cap, int64_t *used, 
  * those never touch the device, whatever was enqueued meanwhile.  A fetch touches only its own engine's streams: with
  * several engines on one GPU (half-batches) fetching one does not wait for the others' runs. */
 int azh_engine_fetch(azh_engine *e);
+/* 1 while work enqueued on this engine's streams is still in flight, 0 when they are idle (< 0: error).  Never waits. */
+int azh_engine_query(azh_engine *e);
 /* How many times azh_engine_drain_json had to fetch by itself (and so waited for the device) since the engine was created:
  * 0 for a host loop that fetches explicitly before every drain sequence. */
 long long azh_engine_implicit_fetches(const azh_engine *e);

@@ -41,7 +41,7 @@ struct orc_engine {
     uint64_t *stats;
     blob *done_head, *done_tail;
     int done_count;
-    int32_t *no_emit;  /* [G] the slot's current game was started by orc_engine_set_positions: counted, not written */
+    int32_t *no_emit;  /* [G] start ply + 1 while the slot's game is one started by orc_engine_set_positions (its record is partial), else 0 */
     uint32_t uid_limit; /* orc_engine_set_game_limit: games with uid >= this are not started (0 = no limit) */
     uint32_t *tt;      /* ORC_FLAG_EVAL_CACHE: [2][G][tt_size] open-addressed table of evaluated nodes, keyed by the board */
     int tt_size;
@@ -263,7 +263,7 @@ void orc_engine_set_positions(orc_engine *e, const uint64_t *boards, const int32
         s->phase = ORC_PHASE_ROOT_EVAL;
         s->ply = plies[g];
         e->force[g] = 0;
-        e->no_emit[g] = 1;
+        e->no_emit[g] = plies[g] + 1;   /* start ply + 1 (the HIP engine's no_emit): the record begins there */
         orc_pos p;
         unpack(e, boards + 2 * (size_t)g, &p);
         make_node(e, g, 0, 0, &p, NULL);
@@ -506,8 +506,10 @@ static void apply_priors(orc_engine *e, int g, const float *logits, int root)
             }
         }
     }
+    /* priors are >= 0 (and never NaN: orc_det_expf is 0 for a NaN argument); stored without a sign like the HIP engine's,
+     * which keeps bit 31 for a mark of its own — the mask changes no value */
     for (int j = 0; j < M; j++)
-        ed[4 * j + 0] = orc_f2u(P[j]);
+        ed[4 * j + 0] = orc_f2u(P[j]) & 0x7FFFFFFFu;
 }
 
 /* step() part 4 (:449-459). */
@@ -536,11 +538,13 @@ static int random_ply_of(const orc_engine *e, uint32_t uid)
     return (int)(((uint64_t)r[0] * 120u) >> 32);
 }
 
-static void finish_game(orc_engine *e, int g, int result)
+/* p0: the first ply the game recorded (0, or the ply a loaded position was at); partial: the game began at a loaded
+ * position (orc_engine_set_positions) — its record lacks the plies before, bit 30 of the header's result word says so */
+static void finish_game(orc_engine *e, int g, int result, int p0, int partial)
 {
     orc_game_state *s = &e->gs[g];
     int64_t size = 16;
-    for (int p = 0; p < s->ply; p++) {
+    for (int p = p0; p < s->ply; p++) {
         const uint8_t *r = REC(e, g, p);
         uint16_t nd;
         memcpy(&nd, r + 18, 2);
@@ -549,12 +553,14 @@ static void finish_game(orc_engine *e, int g, int result)
     blob *b = (blob *)malloc(sizeof(blob) + (size_t)size);
     b->next = NULL;
     b->size = size;
-    int32_t hdr[4] = {g, (int32_t)s->uid, s->ply, result};
+    int32_t hdr[4] = {g, (int32_t)s->uid, s->ply - p0, result};
     if (e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE)
         hdr[3] |= (random_ply_of(e, s->uid) + 1) << 8;
+    if (partial)
+        hdr[3] |= 1 << 30;
     memcpy(b->data, hdr, 16);
     uint8_t *w = b->data + 16;
-    for (int p = 0; p < s->ply; p++) {
+    for (int p = p0; p < s->ply; p++) {
         const uint8_t *r = REC(e, g, p);
         uint16_t nd;
         memcpy(&nd, r + 18, 2);
@@ -718,23 +724,22 @@ static void advance_game(orc_engine *e, int g)
     s->ply += 1;
     e->force[g] = 0;
     int result = (int)(ni2[1] >> 16);
-    if (e->no_emit[g] && (result != 0 || s->ply >= e->cfg.max_plies) &&
-        !((e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE) && result != 0 && random_ply_of(e, s->uid) + 1 >= s->ply)) {
-        /* started from a loaded position: played and counted, not written */
-        if (result != 0) st[ORC_STAT_GAMES]++; else st[ORC_STAT_DROPPED]++;
-        init_game(e, g, s->uid + (uint32_t)e->G);
-    } else if (result != 0 && (e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE) && random_ply_of(e, s->uid) + 1 >= s->ply) {
+    /* a game that began at a loaded position is played and counted like any other; its record (from the loaded ply on)
+     * is handed out marked partial — the self-play callers do not write it, the arena's do (a match from openings) */
+    const int loaded = e->no_emit[g];
+    const int p0 = loaded ? loaded - 1 : 0;
+    if (result != 0 && (e->cfg.flags & ORC_FLAG_ONE_RANDOM_MOVE) && random_ply_of(e, s->uid) + 1 >= s->ply) {
         /* "Skipping game with no board state just after the uniformly random move" (:632-637) */
         st[ORC_STAT_DROPPED]++;
         init_game(e, g, s->uid + (uint32_t)e->G);
     } else if (result != 0) {
-        finish_game(e, g, result);
+        finish_game(e, g, result, p0, loaded != 0);
         st[ORC_STAT_GAMES]++;
         init_game(e, g, s->uid + (uint32_t)e->G);
     } else if (s->ply >= e->cfg.max_plies) {
         st[ORC_STAT_DROPPED]++; /* null-result games are skipped (:628-631) */
         if (e->cfg.flags & ORC_FLAG_KEEP_UNFINISHED)
-            finish_game(e, g, 0); /* arena: "invalid" -> annulled (uai_ringmaster.py:147-150) */
+            finish_game(e, g, 0, p0, loaded != 0); /* arena: "invalid" -> annulled (uai_ringmaster.py:147-150) */
         init_game(e, g, s->uid + (uint32_t)e->G);
     } else {
         s->phase = ORC_PHASE_ROOT_EVAL;

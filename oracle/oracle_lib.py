@@ -189,9 +189,10 @@ def parse_game_record(buf):
         total = int(sum(int(e) >> 16 for e in ents))
         dists.append({move_string(int(e) & 0xFFFF): (int(e) >> 16) / total for e in ents})
     entry = {"boards": boards, "dists": dists, "moves": moves, "result": res & 0xFF}
-    if res >> 8:
-        entry["random_ply"] = (res >> 8) - 1
-    return {"slot": slot, "uid": uid & 0xFFFFFFFF, "entry": entry}
+    if (res >> 8) & 0x3FFFFF:
+        entry["random_ply"] = ((res >> 8) & 0x3FFFFF) - 1
+    # partial: the game began at a loaded position (set_positions); its record starts there
+    return {"slot": slot, "uid": uid & 0xFFFFFFFF, "entry": entry, "partial": bool((res >> 30) & 1)}
 
 
 class Engine:
@@ -262,7 +263,9 @@ class Engine:
         lib().orc_engine_stats(self.h, out.ctypes.data)
         return {n: int(out[i]) for i, n in enumerate(STAT_NAMES)}
 
-    def pop_games(self):
+    def pop_games(self, partial=False):
+        """Finished games since the last call.  Games that began at a loaded position are left out unless `partial` (the
+        self-play callers of the HIP engine do not write them; the arena hands them out)."""
         games = []
         buf = np.zeros(1 << 20, dtype=np.uint8)
         while lib().orc_engine_pending_games(self.h):
@@ -270,5 +273,7 @@ class Engine:
             if n == 0:
                 buf = np.zeros(buf.nbytes * 2, dtype=np.uint8)
                 continue
-            games.append(parse_game_record(bytes(buf[:n])))
+            rec = parse_game_record(bytes(buf[:n]))
+            if partial or not rec["partial"]:
+                games.append(rec)
         return games

@@ -12,7 +12,7 @@ import pytest
 from ataxxzero_amd import arena, link, model
 from oracle import oracle_lib as orc
 from tests.helpers import replay_game_entry, synthetic_evals
-from tests.test_gpu_engine import compare_all
+from tests.test_gpu_engine import _oracle_follow, compare_all
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -94,33 +94,146 @@ def test_batched_two_net_match_bookkeeping():
             assert len(g["moves"]) == 300  # cut -> annulled
 
 
-@pytest.mark.parametrize("dtype,blocks_b", [("f16", 2), ("bf16", 3)])
-def test_two_nets_in_one_tower_launch_equal_two_launches(dtype, blocks_b, monkeypatch):
+@pytest.mark.parametrize("dtype,blocks_b,games,thin", [
+    ("f16", 2, 202, -1),    # at most 512 slots: the engine picks one board per workgroup — k_tower2_pair<Geo2Thin>
+    ("bf16", 3, 202, 0),    # the same engine made to use the 3-board workgroups
+    ("f16", 3, 602, -1),    # more than 512 slots: the 3-board k_tower2_pair, as the first ~490 games of a config-5 match run
+    ("bf16", 2, 602, 1),    # ... and that engine switched to thin batches, as arena.Match does for a match's last games
+])
+def test_two_nets_in_one_tower_launch_equal_two_launches(dtype, blocks_b, games, thin, monkeypatch):
     """The arena's evaluator (uai_ringmaster.py:221-265: each position goes to the net whose move it is): both nets' leaf
     lists in ONE launch of the fused tower (k_tower2_pair; workgroups pick their weight set from the list they serve)
     against the two launches back to back it replaces (AZH_ARENA_PAIR=0) — same games, same trees, every word: a board's
-    result does not depend on which launch carried it.  Nets of different depth included (blocks is per workgroup)."""
+    result does not depend on which launch carried it.  Nets of different depth included (blocks is per workgroup); both
+    geometries of the kernel (3 boards per workgroup, one board per workgroup), each chosen by the engine's size and by hand."""
     wa = model.random_init(2, 128, seed=21)
     wb = model.random_init(blocks_b, 128, seed=22)
+    sample = range(0, games, 7)
     runs = []
     for pair in ("1", "0"):
         monkeypatch.setenv("AZH_ARENA_PAIR", pair)
-        m = arena.Match(wa, wb, visits=12, games=202, dtype=dtype, seed=9, max_plies=80)
+        m = arena.Match(wa, wb, visits=12, games=games, dtype=dtype, seed=9, max_plies=80)
+        m.engine.set_thin_batches(thin)
         lines = []
         for _ in range(8):
             m.run(120)
             lines += m.engine.drain_json()
         m.engine.sync()
-        states = [m.engine.game_state(g).as_tuple() for g in range(202)]
-        trees = [m.engine.tree(g) for g in range(0, 202, 7)]
+        states = [m.engine.game_state(g).as_tuple() for g in range(games)]
+        trees = [m.engine.tree(g) for g in sample]
         runs.append((lines, states, trees, m.engine.stats()))
         m.close()
     (l1, s1, t1, st1), (l0, s0, t0, st0) = runs
-    assert st1 == st0 and st1["plies"] > 202 * 4 and st1["games"] + st1["dropped"] > 50
+    assert st1 == st0 and st1["plies"] > games * 4 and st1["games"] + st1["dropped"] > games // 4
     assert l1 == l0 and s1 == s0
     for a, b in zip(t1, t0):
         for x, y in zip(a, b):
             assert (x == y).all()
+
+
+def _arena_oracle(m, games, visits, seed, max_plies=400):
+    """The oracle engine of an arena.Match: same config, same loaded openings, same game limit."""
+    ocfg = orc.make_config(games=games, visits=visits, seed=seed, fen_str=orc.START_FEN_PLAIN, max_plies=max_plies,
+                           weight=0.0, flags=orc.FLAG_ARENA)
+    for n, _ in orc.Config._fields_:
+        assert getattr(ocfg, n) == getattr(m.engine.cfg, n), n
+    return orc.Engine(ocfg)
+
+
+def _match_in_lock_step(m, oe, net_a, net_b, dtype, thin, rounds, round_iters, sync_rounds, follow_thin_after_switch=False):
+    """arena.Match's own host loop — fetch, enqueue the next round, then parse and score what was fetched, the thin switch
+    decided at a drain (uai_ringmaster.py's drop-in and bench.py's config5 leg run exactly this) — with the oracle following
+    iteration for iteration: every line of every round, and every state and arena word at the rounds in `sync_rounds`.
+    -> (lines, the round after whose drain the match switched to thin batches or None)."""
+    blockers = oe.cfg.blockers
+    lines, switched = [], None
+    followed = 0
+    m.run(round_iters)
+    enqueued = round_iters
+    for r in range(rounds):
+        m.fetch()                                   # waits for the iterations enqueued so far
+        thin_now = thin or (follow_thin_after_switch and switched is not None)
+        if r in sync_rounds:                        # (nothing in flight here: states and arenas can be read)
+            _oracle_follow(oe, net_a, blockers, enqueued - followed, dtype=dtype, thin=thin_now, net_b=net_b)
+            followed = enqueued
+            compare_all(oe, m.engine, range(oe.G))
+        m.run(round_iters)                          # the next round runs while the finished games are parsed and scored
+        if followed < enqueued:
+            _oracle_follow(oe, net_a, blockers, enqueued - followed, dtype=dtype, thin=thin_now, net_b=net_b)
+            followed = enqueued
+        enqueued += round_iters
+        o_chunk = sorted(oe.pop_games(partial=True), key=lambda g: g["uid"])
+        was_thin = m.thin
+        g_chunk = m.drain()
+        if m.thin and not was_thin:
+            switched = r
+        assert len(g_chunk) == len(o_chunk), r
+        for g, rec in zip(g_chunk, o_chunk):
+            opening = g["opening"]
+            assert g["uid"] == rec["uid"] and g["moves"][len(opening):] == rec["entry"]["moves"], r
+            assert g["boards"] == rec["entry"]["boards"] and g["result"] == rec["entry"]["result"], r
+        lines += g_chunk
+    # the round still in flight: the oracle follows it, and its games are the last chunk
+    thin_now = thin or (follow_thin_after_switch and switched is not None)
+    _oracle_follow(oe, net_a, blockers, enqueued - followed, dtype=dtype, thin=thin_now, net_b=net_b)
+    m.fetch()
+    o_chunk = sorted(oe.pop_games(partial=True), key=lambda g: g["uid"])
+    g_chunk = m.drain()
+    assert [(g["uid"], g["moves"][len(g["opening"]):], g["result"]) for g in g_chunk] == \
+           [(rec["uid"], rec["entry"]["moves"], rec["entry"]["result"]) for rec in o_chunk]
+    return lines + g_chunk, switched
+
+
+def test_arena_device_loop_matches_oracle_at_config5_size():
+    """BASELINE configs[4] as bench.py's config5 leg and uai_ringmaster.py's drop-in run it — azh_engine_run_arena: 1000 games
+    in flight, 100 visits per move from a fresh tree, two 12x128 nets, one leaf list per net, a fixed cohort under the game
+    limit (slots go idle), arena.Match's fetch -> run -> drain order and its switch to thin batches once at most 512 games
+    are left — against the oracle's arena mode (engine.py:474-530, uai_ringmaster.py:221-265) whose leaves go to net A or
+    net B by the side to move: every game of every round, every state and arena word at four sync points, one of them after
+    the switch.  f32 towers (bit-identical wherever a board sits; the switch changes no kernel there), and the match starts
+    from random openings of 170 plies (uai_ringmaster.get_opening) so that games end, slots idle and the batch thins
+    within a few thousand iterations instead of forty thousand."""
+    G, V, seed = 1000, 100, 20260101
+    wa, wb = model.random_init(12, 128, seed=1), model.random_init(12, 128, seed=2)
+    m = arena.Match(wa, wb, V, games=G, dtype="f32", seed=seed, opening_depth=170)
+    oe = _arena_oracle(m, G, V, seed)
+    oe.set_positions(np.repeat(m.opening_boards, 2, axis=0), np.full(G, 170, dtype=np.int32))
+    m.set_game_limit(G)
+    oe.set_game_limit(G)
+    rounds = 44
+    lines, switched = _match_in_lock_step(m, oe, m.net_a, m.net_b, link.DTYPE_F32, False, rounds, 50,
+                                          sync_rounds=(1, 14, 29, rounds - 1))
+    compare_all(oe, m.engine, range(G))
+    so, sg = oe.stats(), m.engine.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    idle = sum(m.engine.game_state(g).phase == 3 for g in range(G))
+    assert switched is not None and switched < rounds - 1, (switched, len(lines))   # a sync point lies behind the switch
+    assert len(lines) >= G - link.THIN_MAX_GAMES and idle == len(lines) and sg["ring_overflow"] == 0
+    assert {g["white"] for g in lines} == {"a", "b"} and len({g["result"] for g in lines}) >= 2
+    m.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_arena_thin_pair_kernel_matches_oracle_bit_for_bit(dtype):
+    """The arena's last games as they really run: both nets' leaf lists in one launch of the one-board-per-workgroup tower
+    (k_tower2_pair<Geo2Thin>), 16-bit — pinned to the oracle with azh_net_forward_thin as its evaluator for either net (the
+    thin kernel's result for a board does not depend on where it sits or which launch carries it).  A match that starts
+    above 512 games is followed through its switch: 3-board kernel results cannot be reproduced board by board from the
+    host (a 16-bit board's last bits depend on its slot in the workgroup), so the followed part begins at the switch."""
+    G, V, seed = 384, 24, 77
+    wa, wb = model.random_init(3, 128, seed=31), model.random_init(2, 128, seed=32)
+    m = arena.Match(wa, wb, V, games=G, dtype=dtype, seed=seed, opening_depth=150)
+    oe = _arena_oracle(m, G, V, seed)
+    oe.set_positions(np.repeat(m.opening_boards, 2, axis=0), np.full(G, 150, dtype=np.int32))
+    m.set_game_limit(G)
+    oe.set_game_limit(G)
+    lines, _ = _match_in_lock_step(m, oe, m.net_a, m.net_b, link.DTYPES[dtype], True, 30, 50, sync_rounds=(0, 9, 29))
+    so, sg = oe.stats(), m.engine.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    assert len(lines) > 30 and sg["nn_evals"] > 20 * G and sg["ring_overflow"] == 0
+    m.close()
 
 
 def test_match_from_random_openings(tmp_path):

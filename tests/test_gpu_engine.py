@@ -3,6 +3,7 @@ same evaluator outputs, compared bit for bit: per-game state, whole tree arenas
 (boards, edge priors / visits / scores / children as raw 32-bit patterns), finished
 game records."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from oracle import oracle_lib as orc
 from tests.helpers import replay_game_entry, synthetic_evals
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def make_pair(games, visits, max_plies=400, edges_per_node=96, seed=77, fen=orc.START_FEN_SELFPLAY, weight=0.25,
@@ -22,13 +24,50 @@ def make_pair(games, visits, max_plies=400, edges_per_node=96, seed=77, fen=orc.
     return orc.Engine(ocfg), link.Engine(gcfg)
 
 
-def compare_all(oe, ge, games):
+def _is_nan_bits(w):
+    return ((w & 0x7F800000) == 0x7F800000) & ((w & 0x007FFFFF) != 0)
+
+
+def compare_all(oe, ge, games, nan_aware=False):
+    """nan_aware: a NaN prior or total score must be a NaN on both sides, whatever its sign and payload — the only words of
+    a tree that are not a function of IEEE arithmetic alone (which NaN an operation hands on is the hardware's choice)."""
     for g in games:
         so, sg = oe.game_state(g), ge.game_state(g)
         assert so.as_tuple() == sg.as_tuple(), (g, so.as_tuple(), sg.as_tuple())
         to, tg = oe.tree(g), ge.tree(g)
         for name, a, b in zip(("boards", "info", "edges", "moves"), to, tg):
-            assert a.shape == b.shape and (a == b).all(), (g, name)
+            assert a.shape == b.shape, (g, name)
+            if nan_aware and name == "edges":
+                a, b = a.copy(), b.copy()
+                for col in (0, 2):
+                    na, nb = _is_nan_bits(a[:, col]), _is_nan_bits(b[:, col])
+                    assert (na == nb).all(), (g, name, col)
+                    a[na, col] = b[nb, col] = 0x7FC00000
+            assert (a == b).all(), (g, name)
+
+
+def check_marks(ge, games):
+    """The early request's mark (bit 31 of a prior in the device's edge records, azh_engine_tree_raw): at most ONE marked edge
+    per node, and only on an edge whose child exists, is not a finished position and has 1 .. 128 moves — what lets the
+    descent request the marked child's records without a check.  -> (nodes with a mark, marks on an edge index >= 64)."""
+    marked_nodes = high = 0
+    for g in games:
+        _, info, _, _ = ge.tree(g)
+        raw = ge.tree_raw(g)
+        mark = (raw[:, 0] >> 31) != 0
+        for n in range(len(info)):
+            first, m = int(info[n, 0]), int(info[n, 1] & 0xFFFF)
+            idx = np.nonzero(mark[first:first + m])[0]
+            assert len(idx) <= 1, (g, n, idx.tolist())
+            if len(idx):
+                assert m <= 128, (g, n, m)
+                z, w = int(raw[first + idx[0], 2]), int(raw[first + idx[0], 3])
+                assert (z >> 16) != 0xFFFF and (w >> 31) == 0 and 1 <= ((w >> 23) & 0xFF) <= 128, (g, n, int(idx[0]), hex(z), hex(w))
+                marked_nodes += 1
+                high += int(idx[0]) >= 64
+        # no mark outside the nodes' ranges either (every edge belongs to exactly one node)
+        assert int(mark.sum()) <= len(info)
+    return marked_nodes, high
 
 
 def run_lockstep(oe, ge, iterations, check_every=1, evaluator=synthetic_evals):
@@ -80,6 +119,66 @@ def test_edge_arena_overflow_forces_the_move_like_the_oracle():
     oe, ge = make_pair(games=4, visits=64, edges_per_node=8, seed=9, fen=orc.START_FEN_PLAIN)
     run_lockstep(oe, ge, 300, check_every=10)
     assert oe.stats()["edge_overflow"] > 0 and ge.stats()["edge_overflow"] == oe.stats()["edge_overflow"]
+
+
+def test_marks_of_the_early_request_in_nodes_with_more_than_64_moves():
+    """Mid-game positions (a third of their nodes have 65-128 moves: two edges per lane) searched in lock step with the
+    oracle, then the raw marks: round 5's single store dropped the clear when the newly chosen edge and the previously
+    marked one were 64 apart — the two edges of one lane — and the node kept two marks."""
+    snap = np.load(os.path.join(ROOT, "profiles", "round2_steady_state_positions.npz"))
+    rng = np.random.default_rng(3)
+    cand = np.nonzero((snap["plies"] > 40) & (snap["plies"] < 200))[0]
+    pick = rng.choice(cand, size=48, replace=False)
+    oe, ge = make_pair(games=48, visits=300, seed=6)
+    for e in (oe, ge):
+        e.set_positions(snap["boards"][pick], snap["plies"][pick])
+    run_lockstep(oe, ge, 290, check_every=97)
+    big = sum(int(((ge.tree(g)[1][:, 1] & 0xFFFF) > 64).sum()) for g in range(48))
+    marked, high = check_marks(ge, range(48))
+    assert big > 300 and marked > 1000 and high > 20, (big, marked, high)
+
+
+def test_nan_evaluations_are_never_selected_and_never_read_as_a_mark():
+    """NaN from the evaluator (both references never select a NaN score, cpp/self_play_client.cpp:345-358, engine.py:291).
+    NaN or infinite LOGITS never reach a prior: exp() of the deterministic f32 library returns 0 for them, a row of them
+    gives all-zero priors on both sides — so bit 31 of a stored prior, the descent's mark, is never a NaN's sign (and
+    priors are stored without a sign in any case).  A NaN VALUE makes the total score of every edge on its path NaN: such
+    edges are never selected again, a node whose edges are all NaN falls back to its first move — in lock step with the
+    oracle, marks intact."""
+    neg_nan = np.array([0xFFC00001], dtype=np.uint32).view(np.float32)[0]
+
+    def evaluator(lb):
+        logits, values = synthetic_evals(lb)
+        logits[(lb[:, 0] % np.uint64(5)) == 0] = neg_nan
+        logits[(lb[:, 1] % np.uint64(7)) == 0, 100:300] = -neg_nan     # part of a row, the other sign
+        logits[(lb[:, 1] % np.uint64(11)) == 0, ::3] = np.inf
+        values[(lb[:, 0] % np.uint64(41)) == 0] = neg_nan
+        return logits, values
+
+    oe, ge = make_pair(games=40, visits=60, max_plies=120, seed=15)
+    G = oe.G
+    nan_scores = zero_rows = 0
+    for it in range(1500):
+        n_o, need_o = oe.select()
+        assert ge.select() == n_o
+        logits, values = evaluator(oe.leaf_boards())
+        oe.backup(logits, values)
+        ge.set_evals(logits, values)
+        ge.backup()
+        if it % 250 == 249:
+            compare_all(oe, ge, range(G), nan_aware=True)
+            check_marks(ge, range(G))
+            for g in range(G):
+                _, info, edges, _ = ge.tree(g)
+                assert not _is_nan_bits(edges[:, 0]).any() and not (edges[:, 0] >> 31).any()
+                nan_scores += int(_is_nan_bits(edges[:, 2]).sum())
+                zero_rows += sum(1 for n in range(len(info)) if (info[n, 1] & 0xFFFF) and (info[n, 1] >> 16) == 0 and
+                                 n > 0 and not edges[int(info[n, 0]):int(info[n, 0]) + int(info[n, 1] & 0xFFFF), 0].any())
+        oe.pop_games(), ge.drain_json()
+    so, sg = oe.stats(), ge.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    assert nan_scores > 50 and zero_rows > 50 and so["plies"] > 40, (nan_scores, zero_rows, so["plies"])
 
 
 def test_leaf_features_are_reference_rows():
@@ -177,6 +276,18 @@ def test_overlapped_round_trip_never_waits_for_the_device_inside_the_drain():
         got.append(chunk)
     assert one.implicit_fetches() == 12 and sum(got, []) == want
     assert [len(c) for c in got] == [len(c) for c in seq_rounds]
+    # two engines on one GPU (the half-batches): a fetch of one waits for ITS OWN streams only and copies through pinned
+    # staging — it comes back while the other engine's long run is still in flight (a stream query, not a clock)
+    quick, slow = engine(), engine()
+    quick.run(net, 100, link.DTYPE_F32)
+    quick.sync()
+    slow.run(net, 6000, link.DTYPE_F32)        # about two seconds of search
+    quick.run(net, 100, link.DTYPE_F32)
+    quick.fetch()
+    still_running = slow.busy()
+    quick.drain_json()
+    slow.sync()
+    assert still_running and not slow.busy() and not quick.busy()
 
 
 def test_game_limit_plays_exactly_the_games_below_it_and_then_idles():
@@ -418,19 +529,24 @@ def test_full_size_workload_invariants(name, visits, blocks, net_seed, dtype, fl
     sp.close()
 
 
-def _oracle_follow(oe, net, blockers, iterations):
-    """The oracle plays `iterations` search iterations, its leaves evaluated by the f32 tower (bit-identical wherever a
-    board sits in a launch, tests/test_gpu_net.py), i.e. exactly what the device-resident loop computes for itself."""
+def _oracle_follow(oe, net, blockers, iterations, dtype=link.DTYPE_F32, thin=False, net_b=None):
+    """The oracle plays `iterations` search iterations, its leaves evaluated by the tower the device-resident loop uses for
+    them — the f32 tower, or a 16-bit tower with one board per workgroup (`thin`): both are bit-identical wherever a board
+    sits in a launch (tests/test_gpu_net.py) — i.e. exactly what the loop computes for itself.  `net_b`: the arena's
+    second net, for the leaves whose mover it is (need class 2, uai_ringmaster.py:221-265)."""
     G = oe.G
     logits = np.zeros((G, 833), np.float32)
     values = np.zeros(G, np.float32)
     for _ in range(iterations):
         _, need = oe.select()
-        idx = np.nonzero(need)[0]
-        if len(idx):
-            p, v = net.forward(oe.leaf_boards()[idx], blockers, link.DTYPE_F32)
-            logits[idx] = p.reshape(len(idx), 833)
-            values[idx] = v.reshape(-1)
+        lb = None
+        for cls, n in ((1, net), (2, net_b)):
+            idx = np.nonzero(need == cls)[0] if net_b is not None else (np.nonzero(need)[0] if cls == 1 else [])
+            if len(idx):
+                lb = oe.leaf_boards() if lb is None else lb
+                p, v = n.forward(lb[idx], blockers, dtype, thin=thin)
+                logits[idx] = p.reshape(len(idx), 833)
+                values[idx] = v.reshape(-1)
         oe.backup(logits, values)
 
 
@@ -480,6 +596,8 @@ def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, bl
     for k in so:
         assert so[k] == sg[k], (k, so[k], sg[k])
     assert sg["ring_overflow"] == 0 and so["plies"] >= games
+    marked, _ = check_marks(ge, range(0, games, max(1, games // 256)))   # the early request's marks, as the loop left them
+    assert marked > 0
     if name == "turnover":
         assert len(g_lines) > games // 8 and so["dropped"] > 0 and parked > 0
         assert so["reroot_nodes"] > so["plies"]  # subtrees are really kept across moves
@@ -561,6 +679,37 @@ def test_thin_batch_switch_in_the_device_loop():
         entry = json.loads(line)
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
     sp.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_thin_batch_device_loop_in_16_bits_matches_oracle_bit_for_bit(dtype):
+    """The one-board-per-workgroup tower inside the device-resident loop (engines of at most 512 slots pick it by themselves;
+    arena.Match and the generator switch to it for their last games) pinned to the oracle: the thin kernel is bit-identical
+    wherever a board sits in a launch (tests/test_gpu_net.py), so an oracle whose leaves go through azh_net_forward_thin sees
+    exactly the loop's evaluations — states, arena words, lines, counters.  Both ways of getting there: by size (384 slots)
+    and by azh_engine_set_thin_batches(1) on a larger engine."""
+    dt = link.DTYPES[dtype]
+    conv, bn = model.random_init(3, 128, seed=17)
+    net = link.Net(conv, bn)
+    for games, force in ((384, False), (640, True)):
+        oe, ge = make_pair(games=games, visits=20, max_plies=70, seed=23, select_budget=6)
+        if force:
+            ge.set_thin_batches(1)
+        n_lines = 0
+        for c in range(6):
+            ge.run(net, 200, dt)
+            _oracle_follow(oe, net, oe.cfg.blockers, 200, dtype=dt, thin=True)
+            ge.sync()
+            compare_all(oe, ge, range(games))
+            o_chunk = sorted(oe.pop_games(), key=lambda r: r["uid"])
+            g_chunk = ge.drain_json()
+            assert [json.loads(l) for l in g_chunk] == [r["entry"] for r in o_chunk], c
+            n_lines += len(g_chunk)
+        so, sg = oe.stats(), ge.stats()
+        for k in so:
+            assert so[k] == sg[k], (k, so[k], sg[k])
+        assert n_lines > 20 and so["dropped"] > 0 and so["plies"] > 10 * games
+        ge.close()
 
 
 def test_uid_ordered_emission_is_an_unbiased_prefix():

@@ -49,7 +49,10 @@ if __name__ == "__main__":
              metavar="SEC"),
         flag("--game-count", "size of the match (extension: the reference never stops): the games with uid below N are "
                              "played to completion and scored", type=int, default=1000, metavar="N"),
-        flag("--concurrent", "games in flight on the GPU (extension)", type=int, metavar="N"),
+        flag("--concurrent", "games in flight on the GPU (extension).  Up to 512 the tower runs one board per workgroup from the "
+                             "start, above that the 3-board tower until at most 512 games of the match are left: in 16 bits the two "
+                             "kernels differ in the last bits, so the same --seed reproduces a match game for game only with the "
+                             "same --concurrent and --game-count", type=int, metavar="N"),
         flag("--dtype", "tower arithmetic (extension).  Match play defaults to f16: with a trained net the f16 search picks the f32 "
                         "search's move in 100 %% of test positions, bf16 in 96 %% (DESIGN.md section 5); bf16 is 3-6 %% faster",
              default="f16", choices=["bf16", "f16", "f32"]),
@@ -90,8 +93,12 @@ if __name__ == "__main__":
     cohort = args.game_count
     match.set_game_limit(cohort)   # slots whose cohort games are over go idle: the batch thins out towards the end
     match.run(50)
+    rounds = 0
     while written < cohort:
         match.fetch()              # the games finished so far ...
+        # (every 16th round, between the fetch and the next run, where it waits for nothing: can the match still end?)
+        ended = match.lost_games() if rounds % 16 == 15 else None
+        rounds += 1
         match.run(50)              # ... are parsed, scored and written under the next iterations
         for game in sorted(match.drain(), key=lambda g: g["uid"]):
             if game["uid"] >= cohort:
@@ -110,4 +117,10 @@ if __name__ == "__main__":
             if args.pgn_out:
                 arena.write_game_to_pgn(args.pgn_out, game, names[white], names[black], written, args.tc)
         sys.stdout.flush()
+        if ended is not None and written < cohort:
+            # every game of the cohort has ended on the device (or records were lost) and fewer were handed out: the
+            # missing ones will never come — say so instead of searching an idle engine for ever
+            match.close()
+            print("uai_ringmaster.py: %s; %d of %d games were scored" % (ended, written, cohort), file=sys.stderr)
+            sys.exit(3)   # (the generator CLI's exit code for lost records)
     match.close()
