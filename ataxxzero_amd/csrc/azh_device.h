@@ -134,11 +134,20 @@ __device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
 // code may wait for the other waves.  What the game's 64 lanes hand each other through LDS or global memory needs only
 // this: earlier accesses of the wave are complete (workgroup-scope fence = the waitcnt a __syncthreads() would issue) and
 // the compiler keeps later ones behind it.  LDS and the CU's vector L1 serve a wave's accesses in issue order.
+// (-DAZH_WAVE_SYNC_WAVEFRONT=1: the same at WAVEFRONT scope — no waitcnt at all, the hand-offs no longer wait for the
+// acknowledgement of the wave's global stores.  Every lock-step test passes with it and nothing gets faster — the re-root's
+// passes are bound by their loads, not by its store acknowledgements: profiles/round6_wave_sync_scope_ab.txt.  Not the default.)
 __device__ inline void wave_sync()
 {
+#ifdef AZH_WAVE_SYNC_WAVEFRONT
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
 }
 
 // Cross-lane traffic goes through DPP (VALU speed), not ds_bpermute (an LDS round trip per

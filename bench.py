@@ -40,8 +40,8 @@ SCATTERED_PEAK_GBS = 5300.0   # dependent scattered 672-B reads, >= 8192 chains 
 ITERS_PER_STEP = 250
 TIMING_STRIDE = 8        # every 8th iteration is event-timed (an event is a barrier packet in the queue)
 # rocprofv3 PMC summaries of this very command (tools/prof_bench.sh), per launch of the tower: by half-batches in flight
-PMC_SUMMARY = {2: os.path.join("profiles", "round5_bench_two_half_batches_pmc_k_tower.txt"),
-               1: os.path.join("profiles", "round5_bench_one_batch_pmc_k_tower.txt")}
+PMC_SUMMARY = {2: os.path.join("profiles", "round6_prof_default_two_halves.txt"),
+               1: os.path.join("profiles", "round6_prof_default_one_batch.txt")}
 KERNEL_SOURCE = os.path.join("ataxxzero_amd", "csrc", "net_kernels.hip")
 SNAPSHOT_MEAN_GAME_PLIES = 152.42   # mean length of the 4096 games of the generation the steady-state snapshot was drawn from
                                     # (profiles/round2_steady_state_positions.npz, meta.generation0_mean_plies; 400 sims/move)
@@ -436,7 +436,7 @@ def main():
                     help="comma-separated legs to measure beside the headline (default all): one_batch, target_10k_games, "
                          "target_10k_games_two_half_batches, "
                          "with_eval_cache, target_10k_games_with_eval_cache, with_f16, config1_random_play, config2, config4, "
-                         "config5_arena")
+                         "config5_arena, config5_arena_balanced")
     ap.add_argument("--other-configs-games", type=int, default=0,
                     help="games of the config2 / config4 / config5_arena legs (default: BASELINE's 4096 / 4096 / 1000)")
     ap.add_argument("--arena-ab", action="store_true",
@@ -628,6 +628,12 @@ def main():
         if want("config5_arena") and (default_headline or args.legs != "all"):
             # configs[4]: 1000-game arena of two nets
             out["config5_arena"] = config5_leg(games=og or 1000)
+        if want("config5_arena_balanced") and (default_headline or args.legs != "all"):
+            # the same match between two nets that are a match for each other (seeds 27 : 28: 51 - 49 over a 100-game
+            # pre-match, no game cut, profiles/round6_arena_pairing_search.txt): seed 1 loses 99 % of its games to seed 2
+            # inside 90 plies, and the leg above then mostly prices the one game that is cut at 400 plies
+            out["config5_arena_balanced"] = config5_leg(games=og or 1000, net_seeds=(27, 28))
+        if want("config5_arena") and (default_headline or args.legs != "all"):
             if args.arena_ab:
                 # the same match with the two nets' towers launched one after the other (the round-4 loop), same box, same call
                 os.environ["AZH_ARENA_PAIR"] = "0"

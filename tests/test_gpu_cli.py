@@ -398,7 +398,7 @@ def test_bench_line_carries_every_baseline_config_with_one_definition_of_the_tow
     the legs' own sims/move, nets and dtypes."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--games", "96", "--visits", "8", "--blocks", "1",
                           "--steps", "4", "--warmup", "1", "--iters-per-step", "10", "--phase-fill", "20", "--no-cpu-baseline",
-                          "--no-gemm-ceiling", "--legs", "one_batch,with_f16,config2,config4,config5_arena",
+                          "--no-gemm-ceiling", "--legs", "one_batch,with_f16,config2,config4,config5_arena,config5_arena_balanced",
                           "--other-configs-games", "64", "--arena-ab"], cwd=ROOT, capture_output=True, timeout=900)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     d = json.loads([l for l in res.stdout.decode().splitlines() if l.strip()][-1])
@@ -419,6 +419,16 @@ def test_bench_line_carries_every_baseline_config_with_one_definition_of_the_tow
         assert c["games"] == 64 and c["wall_s"] > 0 and c["mcts_steps_per_s"] > 0 and c["tower_frac_of_peak"] > 0
         assert abs(c["games_per_s"] * c["wall_s"] - 64) < 1e-6
     assert a["score"] == b["score"] and a["mean_plies"] == b["mean_plies"]   # the same match, move for move
+    # what the leg measures, said by the leg (round 6): when 99 % of the games were over, one launch's own rate, and — for a
+    # match that starts with more than 512 games in flight — the rates while at least 512 were live; a second pairing of
+    # two nets that are a match for each other
+    bal = d["config5_arena_balanced"]
+    assert bal["net_seeds"] == [27, 28] and a["net_seeds"] == [1, 2] and bal["games"] == 64
+    for c in (a, b, bal):
+        assert 0 < c["wall_s_until_99pct_games"] <= c["wall_s"] and 0 < c["iterations_until_99pct"] <= c["search_iterations"]
+        assert c["per_launch_frac"] > 0 and abs(c["per_launch_frac"] - c["per_launch_tflops"] / 2500.0) < 1e-12
+        assert c["tower_ms_per_launch"] < c["ms_per_iteration"] * 1.05
+        assert "steps_per_s_while_ge512_live" not in c      # (64 games here: the phase does not exist)
 
 
 def test_bench_py_two_ranks_on_one_gpu():

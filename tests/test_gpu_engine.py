@@ -123,19 +123,39 @@ def test_edge_arena_overflow_forces_the_move_like_the_oracle():
 
 def test_marks_of_the_early_request_in_nodes_with_more_than_64_moves():
     """Mid-game positions (a third of their nodes have 65-128 moves: two edges per lane) searched in lock step with the
-    oracle, then the raw marks: round 5's single store dropped the clear when the newly chosen edge and the previously
-    marked one were 64 apart — the two edges of one lane — and the node kept two marks."""
+    oracle, then the raw marks.  Round 5 moved a mark with ONE store in which a lane chose between setting and clearing: when
+    the newly chosen edge and the previously marked one were 64 apart — the two edges of one lane — the clear was dropped
+    and the node kept two marks.  The evaluator here makes that case the rule: wherever a position has more than 67 moves
+    its 4th and its 68th move (movegen order) get the same, dominant prior, so PUCT alternates between two edges that are
+    exactly 64 apart.  (With round 5's store this test fails on its first check — two marks, on edges 3 and 67 of one node:
+    profiles/round6_mark_collision_test.txt.)"""
     snap = np.load(os.path.join(ROOT, "profiles", "round2_steady_state_positions.npz"))
     rng = np.random.default_rng(3)
     cand = np.nonzero((snap["plies"] > 40) & (snap["plies"] < 200))[0]
     pick = rng.choice(cand, size=48, replace=False)
     oe, ge = make_pair(games=48, visits=300, seed=6)
+    blockers = oe.cfg.blockers
+    forced = [0]
+
+    def evaluator(lb):
+        logits, values = synthetic_evals(lb)
+        for i in range(len(lb)):
+            p = orc.Pos()
+            p.pieces[0], p.pieces[1], p.blockers, p.turn = int(lb[i, 0]), int(lb[i, 1]), blockers, 0   # the mover's moves
+            moves = orc.movegen(p)
+            if len(moves) > 67:
+                logits[i] = -6.0
+                logits[i, orc.lib().orc_policy_index(int(moves[3]))] = 3.0
+                logits[i, orc.lib().orc_policy_index(int(moves[67]))] = 3.0
+                forced[0] += 1
+        return logits, values
+
     for e in (oe, ge):
         e.set_positions(snap["boards"][pick], snap["plies"][pick])
-    run_lockstep(oe, ge, 290, check_every=97)
+    run_lockstep(oe, ge, 290, check_every=97, evaluator=evaluator)
     big = sum(int(((ge.tree(g)[1][:, 1] & 0xFFFF) > 64).sum()) for g in range(48))
     marked, high = check_marks(ge, range(48))
-    assert big > 300 and marked > 1000 and high > 20, (big, marked, high)
+    assert forced[0] > 500 and big > 300 and marked > 1000 and high > 20, (forced[0], big, marked, high)
 
 
 def test_nan_evaluations_are_never_selected_and_never_read_as_a_mark():

@@ -253,9 +253,10 @@ struct Tree {
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        printf("usage: %s trees.bin (tools/sparse_select_dump.py)\n", argv[0]);
+        printf("usage: %s trees.bin [block alignment in 16-byte units: 1 (default) | 8 = a narrow request is ONE 128-byte line]\n", argv[0]);
         return 2;
     }
+    const u32 ALIGN = argc > 2 ? (u32)atoi(argv[2]) : 1u;
     FILE *f = fopen(argv[1], "rb");
     if (!f) {
         printf("cannot open %s\n", argv[1]);
@@ -306,6 +307,7 @@ int main(int argc, char **argv)
                 unmodelled++;
             }
             if (live[n]) {
+                next = (next + ALIGN - 1) / ALIGN * ALIGN;
                 blk[n] = next;
                 next += m + 1;
                 live_nodes++;
@@ -326,7 +328,7 @@ int main(int argc, char **argv)
         gm.root_a = live[0] ? (t.info[0] | ((u32)M[0] << 23)) : 0x80000000u;
         // B: blocks
         const size_t b0 = host_b.size();
-        host_b.resize(b0 + next + 64, make_uint4(0, 0, 0, 0));   // (+64: a wide request of the last block reads past it)
+        host_b.resize(b0 + (next + 64 + 7) / 8 * 8, make_uint4(0, 0, 0, 0));   // (+64: a wide request of the last block reads past it; regions stay 128-byte aligned)
         for (int n = 0; n < t.n_nodes; n++) {
             if (!live[n])
                 continue;
@@ -366,7 +368,7 @@ int main(int argc, char **argv)
     printf("visited children per node, histogram 0..8, 9+:");
     for (int k = 0; k < 10; k++)
         printf(" %.1f%%", 100.0 * hist[k] / live_nodes);
-    printf("\nfootprint per copy: A %.2f GB, B %.2f GB\n", host_a.size() * 16 / 1e9, host_b.size() * 16 / 1e9);
+    printf("\nfootprint per copy: A %.2f GB, B %.2f GB (blocks aligned to %u bytes)\n", host_a.size() * 16 / 1e9, host_b.size() * 16 / 1e9, ALIGN * 16);
 
     const int COPIES = 4;
     uint4 *d_a, *d_b;

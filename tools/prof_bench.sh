@@ -1,10 +1,15 @@
 #!/bin/bash
 # rocprofv3 passes over bench.py itself (run on the GPU box from the repo root):
 # kernel trace + stats of the default bench command, then PMC passes for the dominant kernel.
+#   ARGS="..."      the bench command's arguments (default: the headline, 6 steps)
+#   KERNELS="a b"   kernels to summarise, substrings of their names (default: k_tower k_tree k_advance_list); the first one's
+#                   summary names the sha256 of net_kernels.hip, the others' that of engine.hip
+#   NO_TIMED=1      no "last steps x 250 launches" block (for commands whose kernels of interest are a leg's, not the headline's)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=${OUT:-$R/gpurun_out/prof_bench}
 ARGS=${ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-target-leg --no-gemm-ceiling}
+KERNELS=${KERNELS:-k_tower k_tree k_advance_list}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
@@ -32,15 +37,17 @@ for name in ("k_tower", "k_tree", "k_advance_list"):
 PY
 # every summary names the kernel source it measured: bench.py reports roofline.traffic from a committed summary only while
 # the source it names is the source in the tree
-echo "bench.py $ARGS" > $OUT/summary_k_tower.txt
-echo "kernel source sha256: $(sha256sum $R/ataxxzero_amd/csrc/net_kernels.hip | cut -d' ' -f1)  (ataxxzero_amd/csrc/net_kernels.hip)" >> $OUT/summary_k_tower.txt
-cat $OUT/timed_region.txt >> $OUT/summary_k_tower.txt
-python3 $R/tools/prof_summary.py $OUT k_tower >> $OUT/summary_k_tower.txt 2>&1
-for k in k_tree k_advance_list; do
+first=1
+for k in $KERNELS; do
   echo "bench.py $ARGS" > $OUT/summary_$k.txt
-  echo "kernel source sha256: $(sha256sum $R/ataxxzero_amd/csrc/engine.hip | cut -d' ' -f1)  (ataxxzero_amd/csrc/engine.hip)" >> $OUT/summary_$k.txt
+  if [ $first = 1 ]; then src=net_kernels.hip; else src=engine.hip; fi
+  echo "kernel source sha256: $(sha256sum $R/ataxxzero_amd/csrc/$src | cut -d' ' -f1)  (ataxxzero_amd/csrc/$src)" >> $OUT/summary_$k.txt
+  if [ $first = 1 ] && [ -z "$NO_TIMED" ]; then cat $OUT/timed_region.txt >> $OUT/summary_$k.txt; fi
   python3 $R/tools/prof_summary.py $OUT $k >> $OUT/summary_$k.txt 2>&1
+  first=0
 done
+cp $(ls $OUT/trace/*/*_kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+tail -2 $OUT/trace.log | cut -c1-6000 > $OUT/bench_line_under_the_profiler.txt
 find $OUT -name "*_counter_collection.csv" -delete
 find $OUT -name "*_kernel_trace.csv" -size +8M -delete
 ls -la $OUT

@@ -43,7 +43,9 @@ for i, (ms, ss) in enumerate(zip(mains, sides)):
     late, slack = [], []
     for s0, e0, _, _ in adv:
         k = bisect.bisect_right(starts, s0 + 30000) - 1      # the tower launched beside it (their starts are microseconds apart)
-        if k >= 0:
+        if k >= 0 and e0 - s0 < 5000000 and abs(tw[k][0] - s0) < 200000:
+            # (a re-root launch is matched with the tower that started within 0.2 ms of it; the pairs across a host round
+            # trip — the drain between two steps — are left out)
             late.append(max(0, e0 - tw[k][1]))
             slack.append(tw[k][1] - e0)
     n_late = sum(1 for x in late if x > 0)
