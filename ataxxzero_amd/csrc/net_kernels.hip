@@ -38,6 +38,7 @@
 #include <mutex>
 
 #include "azh_host.h"
+#include "engine_device.h"   // advance_worker: the search loop's queued moves ride in the tower launch's first workgroups
 
 namespace azh {
 
@@ -148,6 +149,26 @@ struct TowerArgs {
     int sym;                 // 1: test-time symmetry averaging (nn_evals.py:48-62): virtual board v is list entry
                              // v >> 3 under dihedral symmetry v & 7; outputs are indexed by v, not by game
 };
+
+// The device-resident search loop plays its queued moves (sample, record, re-root: advance_game, engine_device.h) in the FIRST
+// H.workers workgroups of the tower launch: they are dispatched before any tile's workgroup, so the re-roots start with the
+// launch instead of waiting beside it for a slot the tower never leaves, and the loop needs no side stream and no cross-stream
+// events.  A worker runs one wave (the others return), uses the workgroup's LDS as its scratch, and is gone after ~0.1 ms; the
+// tiles are numbered from workgroup H.workers on (H.workers is a multiple of 8: a tile keeps its XCD).  true: this
+// workgroup was a worker and is done.  H.workers = 0 (every launch outside that loop): nothing happens.
+__device__ inline bool tower_prologue(const AdvanceHook &H, unsigned char *smem, int &wg)
+{
+    wg = (int)blockIdx.x;
+    if (H.workers == 0)
+        return false;
+    if (wg < H.workers) {
+        if (threadIdx.x < WAVE)
+            advance_worker(H.P, smem, wg, H.workers);
+        return true;
+    }
+    wg -= H.workers;
+    return false;
+}
 
 // apply_symmetry (nn_evals.py:8-16): cell (x, y) of the transformed tensor shows cell (ox, oy) of the original
 __device__ __host__ inline void sym_cell(int s, int x, int y, int &ox, int &oy)
@@ -424,16 +445,19 @@ __device__ inline void conv_layer(unsigned char *lds, int in_img, int out_img, b
 }
 
 template <int DT, int NB, int WPS, bool STAMP = false, int FT = F>
-__global__ __launch_bounds__(64 * (FT / 32), WPS) void k_tower(TowerArgs A)
+__global__ __launch_bounds__(64 * (FT / 32), WPS) void k_tower(TowerArgs A, AdvanceHook H)
 {
     typedef Traits<DT> Tr;
     typedef Geo<DT, NB, FT> G;
     constexpr int OCT = G::OCTF, NTHREADS = G::NTHR, F = FT;  // shadow the 128-filter constants of the fast path
     typedef typename Tr::afrag afrag;
     extern __shared__ __align__(16) unsigned char smem[];
+    int wg;
+    if (tower_prologue(H, smem, wg))
+        return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
-    const int tile0 = blockIdx.x * G::BOARDS;
+    const int tile0 = wg * G::BOARDS;
     if (tile0 >= n)
         return;
     const int nb = (n - tile0) < G::BOARDS ? (n - tile0) : G::BOARDS;
@@ -442,7 +466,7 @@ __global__ __launch_bounds__(64 * (FT / 32), WPS) void k_tower(TowerArgs A)
     // diagnostic stamps (STAMP builds only): 4 per layer {loop start, loop end, epilogue end, barrier passed}
     unsigned long long *st = nullptr;
     if constexpr (STAMP) {
-        st = A.stamps + ((size_t)blockIdx.x * OCT + wave) * 128;
+        st = A.stamps + ((size_t)wg * OCT + wave) * 128;
         st[0] = stamp_now();
     }
 
@@ -1305,22 +1329,28 @@ __device__ __forceinline__ void tower2_run(const TowerArgs &A, unsigned char *sm
 }
 
 template <int DT, bool STAMP = false>
-__global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A)
+__global__ __launch_bounds__(NTHREADS, 2) void k_tower2(TowerArgs A, AdvanceHook H)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    int wg;
+    if (tower_prologue(H, smem, wg))
+        return;
     const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
-    const int tile0 = blockIdx.x * Geo2::BOARDS;
+    const int tile0 = wg * Geo2::BOARDS;
     if (tile0 >= n)
         return;
     tower2_run<DT, STAMP>(A, smem, tile0, n);
 }
 
 template <int DT>
-__global__ __launch_bounds__(NTHREADS, 2) void k_tower2_thin(TowerArgs A)
+__global__ __launch_bounds__(NTHREADS, 2) void k_tower2_thin(TowerArgs A, AdvanceHook H)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    int wg;
+    if (tower_prologue(H, smem, wg))
+        return;
     const int n = (A.count ? *A.count : A.n) * (A.sym ? 8 : 1);
-    const int tile0 = blockIdx.x;
+    const int tile0 = wg;
     if (tile0 >= n)
         return;
     tower2_run<DT, false, Geo2Thin>(A, smem, tile0, n);
@@ -1333,12 +1363,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2_thin(TowerArgs A)
 // board's result is bit for bit that of the single-net launch.  Two third-full launches back to back become one launch
 // whose workgroups all start together: at 2 x 500 leaves the iteration's evaluator time halves.
 template <int DT, typename G = Geo2>
-__global__ __launch_bounds__(NTHREADS, 2) void k_tower2_pair(TowerArgs A, TowerArgs B)
+__global__ __launch_bounds__(NTHREADS, 2) void k_tower2_pair(TowerArgs A, TowerArgs B, AdvanceHook H)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    int wg;
+    if (tower_prologue(H, smem, wg))
+        return;
     const int na = *A.count;
     const int wga = (na + G::BOARDS - 1) / G::BOARDS;
-    const bool second = (int)blockIdx.x >= wga;
+    const bool second = wg >= wga;
     TowerArgs X = A;
     if (second) {
         X.conv_w2 = B.conv_w2;
@@ -1350,7 +1383,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_tower2_pair(TowerArgs A, TowerA
         X.list = B.list;
     }
     const int n = second ? *B.count : na;
-    const int tile0 = ((int)blockIdx.x - (second ? wga : 0)) * G::BOARDS;
+    const int tile0 = (wg - (second ? wga : 0)) * G::BOARDS;
     if (tile0 >= n)
         return;
     tower2_run<DT, false, G>(X, smem, tile0, n);
@@ -1639,8 +1672,14 @@ extern "C" void azh_net_destroy(azh_net *net)
 }
 
 
+static const AdvanceHook &no_hook()
+{
+    static const AdvanceHook h = {};   // workers = 0
+    return h;
+}
+
 template <int DT, int NB, int WPS, bool STAMP = false, int FT = F>
-static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
+static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream, const AdvanceHook &H = no_hook())
 {
     typedef Geo<DT, NB, FT> G;
     static_assert(G::LDS_BYTES <= 160 * 1024, "tower image does not fit one CU's LDS");
@@ -1653,17 +1692,18 @@ static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream)
                                     G::LDS_BYTES));
         attr_set[dev] = true;
     }
-    const int grid = (max_n + G::BOARDS - 1) / G::BOARDS;
+    const int grid = (max_n + G::BOARDS - 1) / G::BOARDS + H.workers;
     if (grid <= 0)
         return 0;
-    hipLaunchKernelGGL((k_tower<DT, NB, WPS, STAMP, FT>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL((k_tower<DT, NB, WPS, STAMP, FT>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES, stream, args, H);
     AZH_HIP(hipGetLastError());
     return 0;
 }
 
 // Boards per workgroup for the 16-bit towers: 3 (two workgroups per CU) unless
 // AZH_TOWER_BOARDS=6 asks for one 6-board workgroup per CU.
-template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &args, int max_n, hipStream_t stream)
+template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &args, int max_n, hipStream_t stream,
+                                                               const AdvanceHook &H = no_hook())
 {
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
@@ -1674,16 +1714,16 @@ template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &
                                     Geo2::LDS_BYTES));
         attr_set[dev] = true;
     }
-    const int grid = (max_n + Geo2::BOARDS - 1) / Geo2::BOARDS;
+    const int grid = (max_n + Geo2::BOARDS - 1) / Geo2::BOARDS + H.workers;
     if (grid <= 0)
         return 0;
-    hipLaunchKernelGGL((k_tower2<DT, STAMP>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL((k_tower2<DT, STAMP>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args, H);
     AZH_HIP(hipGetLastError());
     return 0;
 }
 
 // one board per workgroup (Geo2Thin): the launch for a handful of boards
-template <int DT> static int launch_tower2_thin(const TowerArgs &args, int max_n, hipStream_t stream)
+template <int DT> static int launch_tower2_thin(const TowerArgs &args, int max_n, hipStream_t stream, const AdvanceHook &H = no_hook())
 {
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
@@ -1693,9 +1733,9 @@ template <int DT> static int launch_tower2_thin(const TowerArgs &args, int max_n
         AZH_HIP(hipFuncSetAttribute((const void *)k_tower2_thin<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo2::LDS_BYTES));
         attr_set[dev] = true;
     }
-    if (max_n <= 0)
+    if (max_n + H.workers <= 0)
         return 0;
-    hipLaunchKernelGGL((k_tower2_thin<DT>), dim3(max_n), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL((k_tower2_thin<DT>), dim3(max_n + H.workers), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args, H);
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -1758,26 +1798,28 @@ __global__ __launch_bounds__(256) void k_sym_reduce(const float *__restrict__ sy
 // first n boards when both are null).  Everything is indexed by game.
 static int net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                       const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym, int thin = 0);
+                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym, int thin = 0,
+                      const void *hook = nullptr);
 
 // thin: the caller expects a handful of boards (<= 512): one board per workgroup (Geo2Thin) where that kernel applies
 int azh_net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                    const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                   float *d_values, hipStream_t stream, unsigned long long *d_stamps, int thin)
+                   float *d_values, hipStream_t stream, unsigned long long *d_stamps, int thin, const void *advance_hook)
 {
-    return net_launch(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_logits, d_values, stream, d_stamps, 0, thin);
+    return net_launch(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_logits, d_values, stream, d_stamps, 0, thin,
+                      advance_hook);
 }
 
 // Symmetry-averaged evaluation: the tower runs 8 * n virtual boards into the scratch arrays
 // (d_tmp_logits [8 max_n][833], d_tmp_values [8 max_n]), k_sym_reduce writes the averages by game.
 int azh_net_launch_sym(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                        const int *d_count, int max_n, unsigned long long blockers, float *d_tmp_logits,
-                       float *d_tmp_values, float *d_logits, float *d_values, hipStream_t stream, int thin)
+                       float *d_tmp_values, float *d_logits, float *d_values, hipStream_t stream, int thin, const void *advance_hook)
 {
     if (max_n <= 0)
         return 0;
     int rc = net_launch(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_tmp_logits, d_tmp_values, stream,
-                        nullptr, 1, thin);
+                        nullptr, 1, thin, advance_hook);
     if (rc)
         return rc;
     hipLaunchKernelGGL(k_sym_reduce, dim3(max_n), dim3(256), 0, stream, (const float *)d_tmp_logits,
@@ -1816,7 +1858,8 @@ static TowerArgs tower_args(const azh_net *net, int dtype, const unsigned long l
 // then launches the two nets one after the other.  max_n bounds count_a + count_b (a game has one leaf).
 int azh_net_launch_pair(azh_net *net_a, azh_net *net_b, int dtype, const unsigned long long *d_boards, const int *d_list_a,
                         const int *d_count_a, const int *d_list_b, const int *d_count_b, int max_n,
-                        unsigned long long blockers, float *d_logits, float *d_values, hipStream_t stream, int thin)
+                        unsigned long long blockers, float *d_logits, float *d_values, hipStream_t stream, int thin,
+                        const void *advance_hook)
 {
     if (dtype != AZH_DTYPE_BF16 && dtype != AZH_DTYPE_F16)
         return 1;
@@ -1842,12 +1885,13 @@ int azh_net_launch_pair(azh_net *net_a, azh_net *net_b, int dtype, const unsigne
         attr_set[dev][k] = true;
     }
     // ceil(nA / B) + ceil(nB / B) <= (nA + nB) / B + 2 workgroups of B boards (B = 3, or 1 for thin batches)
-    const int grid = max_n / (thin ? Geo2Thin::BOARDS : Geo2::BOARDS) + 2;
+    const AdvanceHook &H = advance_hook ? *static_cast<const AdvanceHook *>(advance_hook) : no_hook();
+    const int grid = max_n / (thin ? Geo2Thin::BOARDS : Geo2::BOARDS) + 2 + H.workers;
     switch (k) {
-    case 0: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b); break;
-    case 1: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b); break;
-    case 2: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16, Geo2Thin>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b); break;
-    default: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16, Geo2Thin>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b); break;
+    case 0: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b, H); break;
+    case 1: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b, H); break;
+    case 2: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16, Geo2Thin>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b, H); break;
+    default: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16, Geo2Thin>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b, H); break;
     }
     AZH_HIP(hipGetLastError());
     return 0;
@@ -1855,10 +1899,11 @@ int azh_net_launch_pair(azh_net *net_a, azh_net *net_b, int dtype, const unsigne
 
 static int net_launch(azh_net *net, int dtype, const unsigned long long *d_boards, const int *d_list,
                       const int *d_count, int max_n, unsigned long long blockers, float *d_logits,
-                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym, int thin)
+                      float *d_values, hipStream_t stream, unsigned long long *d_stamps, int sym, int thin, const void *hook)
 {
     if (dtype < 0 || dtype > 2)
         return azh_fail(-2, "bad dtype %d", dtype);
+    const AdvanceHook &H = hook ? *static_cast<const AdvanceHook *>(hook) : no_hook();
     if (net_pack(net, dtype))
         return -1;
     TowerArgs a = tower_args(net, dtype, d_boards, d_list, d_count, max_n, blockers, d_logits, d_values, d_stamps, sym);
@@ -1871,15 +1916,15 @@ static int net_launch(azh_net *net, int dtype, const unsigned long long *d_board
             return azh_fail(-2, "stamps are built for the 128-filter bf16 tower only");
         if (net->filters == 64) {
             switch (dtype) {
-            case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 3, 1, false, 64>(a, max_n, stream);
-            case AZH_DTYPE_BF16: return launch_tower<AZH_DTYPE_BF16, 3, 1, false, 64>(a, max_n, stream);
-            default: return launch_tower<AZH_DTYPE_F16, 3, 1, false, 64>(a, max_n, stream);
+            case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 3, 1, false, 64>(a, max_n, stream, H);
+            case AZH_DTYPE_BF16: return launch_tower<AZH_DTYPE_BF16, 3, 1, false, 64>(a, max_n, stream, H);
+            default: return launch_tower<AZH_DTYPE_F16, 3, 1, false, 64>(a, max_n, stream, H);
             }
         }
         switch (dtype) {
-        case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 1, 2, false, 256>(a, max_n, stream);
-        case AZH_DTYPE_BF16: return launch_tower<AZH_DTYPE_BF16, 3, 2, false, 256>(a, max_n, stream);
-        default: return launch_tower<AZH_DTYPE_F16, 3, 2, false, 256>(a, max_n, stream);
+        case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 1, 2, false, 256>(a, max_n, stream, H);
+        case AZH_DTYPE_BF16: return launch_tower<AZH_DTYPE_BF16, 3, 2, false, 256>(a, max_n, stream, H);
+        default: return launch_tower<AZH_DTYPE_F16, 3, 2, false, 256>(a, max_n, stream, H);
         }
     }
     const bool six = tower_boards() == 6;
@@ -1890,26 +1935,26 @@ static int net_launch(azh_net *net, int dtype, const unsigned long long *d_board
 #endif
     if (v2) {
         if (d_stamps)
-            return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16, true>(a, max_n, stream)
+            return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16, true>(a, max_n, stream, H)
                                            : azh_fail(-2, "stamps are built for bf16 only");
         if (thin)
-            return dtype == AZH_DTYPE_BF16 ? launch_tower2_thin<AZH_DTYPE_BF16>(a, max_n, stream)
-                                           : launch_tower2_thin<AZH_DTYPE_F16>(a, max_n, stream);
-        return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16>(a, max_n, stream)
-                                       : launch_tower2<AZH_DTYPE_F16>(a, max_n, stream);
+            return dtype == AZH_DTYPE_BF16 ? launch_tower2_thin<AZH_DTYPE_BF16>(a, max_n, stream, H)
+                                           : launch_tower2_thin<AZH_DTYPE_F16>(a, max_n, stream, H);
+        return dtype == AZH_DTYPE_BF16 ? launch_tower2<AZH_DTYPE_BF16>(a, max_n, stream, H)
+                                       : launch_tower2<AZH_DTYPE_F16>(a, max_n, stream, H);
     }
     if (d_stamps) {  // diagnostic instantiations (bf16 only)
         if (dtype != AZH_DTYPE_BF16)
             return azh_fail(-2, "stamps are built for bf16 only");
-        return six ? launch_tower<AZH_DTYPE_BF16, 6, 1, true>(a, max_n, stream)
-                   : launch_tower<AZH_DTYPE_BF16, 3, 2, true>(a, max_n, stream);
+        return six ? launch_tower<AZH_DTYPE_BF16, 6, 1, true>(a, max_n, stream, H)
+                   : launch_tower<AZH_DTYPE_BF16, 3, 2, true>(a, max_n, stream, H);
     }
     switch (dtype) {
-    case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 3, 1>(a, max_n, stream);
+    case AZH_DTYPE_F32: return launch_tower<AZH_DTYPE_F32, 3, 1>(a, max_n, stream, H);
     case AZH_DTYPE_BF16:
-        return six ? launch_tower<AZH_DTYPE_BF16, 6, 1>(a, max_n, stream) : launch_tower<AZH_DTYPE_BF16, 3, 2>(a, max_n, stream);
+        return six ? launch_tower<AZH_DTYPE_BF16, 6, 1>(a, max_n, stream, H) : launch_tower<AZH_DTYPE_BF16, 3, 2>(a, max_n, stream, H);
     default:
-        return six ? launch_tower<AZH_DTYPE_F16, 6, 1>(a, max_n, stream) : launch_tower<AZH_DTYPE_F16, 3, 2>(a, max_n, stream);
+        return six ? launch_tower<AZH_DTYPE_F16, 6, 1>(a, max_n, stream, H) : launch_tower<AZH_DTYPE_F16, 3, 2>(a, max_n, stream, H);
     }
 }
 

@@ -578,12 +578,17 @@ def _oracle_follow(oe, net, blockers, iterations, dtype=link.DTYPE_F32, thin=Fal
     ("bench-size", 4096, 400, 12, 400, 48, 3, 150),  # bench.py's workload: 4096 games, 400 sims/move, 12x128
     ("two-rounds", 8203, 8, 1, 60, 6, 2, 40),        # more games than resident waves (8192): one game per workgroup,
                                                      # a need-bit mask with a ragged last word
+    ("turnover-side-stream", 512, 12, 2, 90, 6, 12, 250),   # rounds 3-5's loop (AZH_REROOT_SIDE_STREAM=1): the queued moves as
+                                                            # k_advance_list on a side stream behind events
 ])
-def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, blocks, max_plies, budget, chunks, chunk):
-    """The loop bench.py and the CLI run — azh_engine_run: fused k_tree, queued re-roots on the side stream behind
-    events, parked descents — against the oracle, iteration for iteration: every game state, every arena word and every
-    JSON line.  (The step-wise API the other lock-step tests drive shares the device functions but not the launch
-    structure or the stream ordering.)"""
+def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, blocks, max_plies, budget, chunks, chunk, monkeypatch):
+    """The loop bench.py and the CLI run — azh_engine_run: fused k_tree, the queued moves played by the first workgroups of
+    the tower launch, parked descents — against the oracle, iteration for iteration: every game state, every arena word and
+    every JSON line.  (The step-wise API the other lock-step tests drive shares the device functions but not the launch
+    structure.)"""
+    if name.endswith("side-stream"):
+        monkeypatch.setenv("AZH_REROOT_SIDE_STREAM", "1")
+        name = name[:-len("-side-stream")]
     conv, bn = model.random_init(blocks, 128, seed=7)
     net = link.Net(conv, bn)
     oe, ge = make_pair(games=games, visits=visits, max_plies=max_plies, seed=99, select_budget=budget)
