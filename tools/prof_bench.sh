@@ -2,14 +2,15 @@
 # rocprofv3 passes over bench.py itself (run on the GPU box from the repo root):
 # kernel trace + stats of the default bench command, then PMC passes for the dominant kernel.
 #   ARGS="..."      the bench command's arguments (default: the headline, 6 steps)
-#   KERNELS="a b"   kernels to summarise, substrings of their names (default: k_tower k_tree k_advance_list); the first one's
+#   KERNELS="a b"   kernels to summarise, substrings of their names (default: k_tower k_tree — since round 6 the queued moves are
+#                   played inside the tower launch; AZH_REROOT_SIDE_STREAM=1 brings k_advance_list back); the first one's
 #                   summary names the sha256 of net_kernels.hip, the others' that of engine.hip
 #   NO_TIMED=1      no "last steps x 250 launches" block (for commands whose kernels of interest are a leg's, not the headline's)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=${OUT:-$R/gpurun_out/prof_bench}
 ARGS=${ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-target-leg --no-gemm-ceiling}
-KERNELS=${KERNELS:-k_tower k_tree k_advance_list}
+KERNELS=${KERNELS:-k_tower k_tree}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
@@ -27,7 +28,7 @@ f = max(glob.glob(os.path.join(sys.argv[1], "trace", "*", "*_kernel_trace.csv"))
 m = re.search(r"--steps (\d+)", sys.argv[2])
 h = re.search(r"--streams (\d+)", sys.argv[2])
 n = (int(m.group(1)) if m else 40) * 250 * (int(h.group(1)) if h else 2)   # bench.py's default: two half-batches in flight
-for name in ("k_tower", "k_tree", "k_advance_list"):
+for name in ("k_tower", "k_tree", "k_advance_list"):   # (k_advance_list: side-stream mode only)
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if name in r["Kernel_Name"]]
     d = d[-n:]
     if not d:
