@@ -14,7 +14,7 @@
 // batch is the number of concurrent games.  The device-resident loop (run_loop) runs an
 // iteration as TWO launches on one stream — the fused tower, then k_tree = backup + mark + the
 // next select + the leaf-list compaction, one wave per game, four games per workgroup — with the
-// queued re-roots (k_advance_list) on a side stream under the next tower.  The step-wise API
+// queued moves (advance_game, engine_device.h) played by the first workgroups of the tower launch.  The step-wise API
 // (azh_engine_select / _backup, used by the lock-step parity tests and the reference ABI) runs
 // the same device functions as separate kernels: k_select -> k_compact -> k_advance_list ->
 // (evaluator) -> k_backup -> k_mark.
@@ -167,7 +167,7 @@ __device__ inline int select_game(const EngineParams &P, int g, azh_game_state &
     u64 leaf_mover = 0, leaf_opp = 0;
 
     if (s.phase >= 2) {
-        // 2: the move of this game is due: its re-root runs after this select (k_advance_list), no leaf now
+        // 2: the move of this game is due: its re-root runs after this select (the next tower launch's first workgroups), no leaf now
         // 3: the slot is idle (azh_engine_set_game_limit: every game it was to play has been played)
         kind = AZH_LEAF_NONE;
     } else if (s.phase == 0 && (P.flags & AZH_FLAG_TWO_NETS) && (A.ni[0].y & 0xFFFFu) == 1u) {
@@ -1021,7 +1021,7 @@ struct azh_engine {
     azh_config cfg;
     EngineParams P;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // queued re-roots (k_advance_list) of the device loop
+    hipStream_t stream2 = nullptr;            // AZH_REROOT_SIDE_STREAM=1 only: queued re-roots (k_advance_list) beside the tower, rounds 3-5's loop
     hipEvent_t ev_sel = nullptr, ev_adv = nullptr;
     std::vector<void *> allocs;
     float *d_feat = nullptr;
@@ -1361,18 +1361,31 @@ static int enqueue_compact(azh_engine *e)
 
 // Device-resident loop.  Iteration = select -> tower -> backup -> "is the move due?"; consecutive iterations run
 // backup + mark + the next select of one game in a single fused launch (k_tree), and the queued re-roots
-// (k_advance_list) on the side stream under the next tower.
-static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations)
-{
-    if (iterations <= 0)
-        return 0;
-    const int two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
-    // arena: the two nets' towers as one launch (AZH_ARENA_PAIR=0: two launches back to back, for A/B runs)
-    const char *pair_s = getenv("AZH_ARENA_PAIR");  // (read per call: a test switches it inside one process)
-    const bool pair_env = !(pair_s && atoi(pair_s) == 0);
-    const bool pair = pair_env && two && !(e->P.flags & AZH_FLAG_SYMMETRY_AVG);
+// inside the tower launch that follows (its first workgroups).
+//
+// The queued moves (sample, record, re-root: advance_game) are played by the first workgroups of the tower launch that
+// follows the tree launch which queued them — dispatched before any tile's workgroup, done after ~0.1 ms, and the next
+// tree launch, behind the tower on the same stream, finds every move played: one stream, two launches per iteration.
+// Rounds 3-5 ran them as k_advance_list on a high-priority side stream beside the tower, with the tree launches' and
+// its own completion signals as cross-stream events: the tower leaves no wave slot and no LDS beside itself, so that
+// launch spent most of its 0.2-0.5 ms waiting for the tower's first workgroups to retire (and outlasted the tower in
+// 5-9 % of the iterations), and the event machinery cost an iteration 7-10 us with nothing queued
+// (profiles/round6_reroots_in_the_tower_launch.txt).  AZH_REROOT_SIDE_STREAM=1 runs that loop (A/B runs; read per call).
+//
+// A run is enqueued as begin() + `iterations` x iteration(): azh_engine_run does that for one engine, azh_engines_run for
+// several with their iterations interleaved, so that the half-batches of a GPU all start with the first launches enqueued
+// instead of one after the other's whole run.
+struct RunLoop {
+    azh_engine *e;
+    azh_net *net_a, *net_b;
+    int dtype, iterations;
+    int two = 0;
+    bool pair = false, side = false;
+    AdvanceHook hook;
+
     // one fused tree launch; ev (or nullptr) is signalled by the kernel's own completion
-    auto launch_tree = [&](bool stamped, int mode, hipEvent_t ev) {
+    void launch_tree(bool stamped, int mode, hipEvent_t ev)
+    {
         const bool small = e->P.G <= TREE_ONE_ROUND_GAMES;
         const int waves = small ? TREE_WAVES_SMALL : TREE_WAVES_LARGE;
         const dim3 grid((e->P.G + waves - 1) / waves), block(waves * WAVE);
@@ -1384,33 +1397,36 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
             hipExtLaunchKernelGGL((k_tree<false, TREE_WAVES_SMALL>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
         else
             hipExtLaunchKernelGGL((k_tree<false, TREE_WAVES_LARGE>), grid, block, 0, e->stream, nullptr, ev, 0, e->P, mode, two);
-    };
-    // The queued moves (sample, record, re-root: advance_game) are played by the first workgroups of the tower launch that
-    // follows the tree launch which queued them — dispatched before any tile's workgroup, done after ~0.1 ms, and the next
-    // tree launch, behind the tower on the same stream, finds every move played: one stream, two launches per iteration.
-    // Rounds 3-5 ran them as k_advance_list on a high-priority side stream beside the tower, with the tree launches' and
-    // its own completion signals as cross-stream events: the tower leaves no wave slot and no LDS beside itself, so that
-    // launch spent most of its 0.2-0.5 ms waiting for the tower's first workgroups to retire (and outlasted the tower in
-    // 5-9 % of the iterations), and the event machinery cost an iteration 7-10 us with nothing queued
-    // (profiles/round6_reroots_in_the_tower_launch.txt).  AZH_REROOT_SIDE_STREAM=1 runs that loop (A/B runs; read per call).
-    const char *side_s = getenv("AZH_REROOT_SIDE_STREAM");
-    const bool side = side_s && atoi(side_s) != 0;
-    AdvanceHook hook;
-    hook.workers = e->adv_workers;
-    hook.P = e->P;
-    e->unfetched_work = true;  // (every path that can finish a game goes through a re-root)
-    launch_tree(false, 2, side ? e->ev_sel : nullptr);  // select + leaf list
+    }
     // side-stream mode: ev_sel is signalled by the tree launch itself, ev_adv by the re-root launch (hipExtLaunchKernelGGL's
     // stop event: no event-record packets at the kernel boundaries of the main stream)
-    auto side_advance = [&]() -> int {
+    int side_advance()
+    {
         if (!side)
             return 0;
         AZH_HIP(hipStreamWaitEvent(e->stream2, e->ev_sel, 0));
         return enqueue_advance(e, e->stream2, e->ev_adv);
-    };
-    if (side_advance()) return -1;
-    const AdvanceHook *moves = side ? nullptr : &hook;
-    for (int it = 0; it < iterations; it++) {
+    }
+
+    int begin()
+    {
+        two = (e->P.flags & AZH_FLAG_TWO_NETS) && e->arena_lists;  // one leaf list per net
+        // arena: the two nets' towers as one launch (AZH_ARENA_PAIR=0: two launches back to back, for A/B runs)
+        const char *pair_s = getenv("AZH_ARENA_PAIR");  // (read per call: a test switches it inside one process)
+        const bool pair_env = !(pair_s && atoi(pair_s) == 0);
+        pair = pair_env && two && !(e->P.flags & AZH_FLAG_SYMMETRY_AVG);
+        const char *side_s = getenv("AZH_REROOT_SIDE_STREAM");
+        side = side_s && atoi(side_s) != 0;
+        hook.workers = e->adv_workers;
+        hook.P = e->P;
+        e->unfetched_work = true;  // (every path that can finish a game goes through a re-root)
+        launch_tree(false, 2, side ? e->ev_sel : nullptr);  // select + leaf list
+        return side_advance();
+    }
+
+    int iteration(int it)
+    {
+        const AdvanceHook *moves = side ? nullptr : &hook;
         const bool rec = e->timing_stride > 0 && e->loop_iter % e->timing_stride == 0 && e->samples < MAX_TIMED_SAMPLES;
         hipEvent_t *ev = rec ? &e->events[3 * e->samples] : nullptr;
         if (e->close_pending) {
@@ -1457,8 +1473,43 @@ static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, in
             }
         }
         e->loop_iter++;
+        return 0;
     }
-    return 0;
+};
+
+static int run_loop(azh_engine *e, azh_net *net_a, azh_net *net_b, int dtype, int iterations)
+{
+    if (iterations <= 0)
+        return 0;
+    RunLoop L{e, net_a, net_b, dtype, iterations};
+    int rc = L.begin();
+    for (int it = 0; it < iterations && rc == 0; it++)
+        rc = L.iteration(it);
+    return rc;
+}
+
+// The same run for several engines of one GPU (the half-batches of selfplay.SelfPlay), their iterations enqueued in turn:
+// enqueueing engine after engine lets the second one start only when the first one's whole run — two launches per iteration,
+// a few milliseconds of host time per 250 iterations — has been enqueued, and finish that much later, alone on the chip.
+extern "C" int azh_engines_run(azh_engine *const *engines, int n, azh_net *net, int dtype, int iterations)
+{
+    if (!engines || n < 1 || !net || iterations < 0)
+        return azh_fail(-1, "azh_engines_run: bad argument");
+    for (int i = 0; i < n; i++)
+        if (!engines[i])
+            return azh_fail(-1, "azh_engines_run: null engine");
+    if (iterations == 0)
+        return 0;
+    std::vector<RunLoop> loops;
+    for (int i = 0; i < n; i++)
+        loops.push_back(RunLoop{engines[i], net, nullptr, dtype, iterations});
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; i++)
+        rc = loops[i].begin();
+    for (int it = 0; it < iterations && rc == 0; it++)
+        for (int i = 0; i < n && rc == 0; i++)
+            rc = loops[i].iteration(it);
+    return rc;
 }
 
 extern "C" int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations)
@@ -1755,8 +1806,8 @@ static int fetch_records(azh_engine *e)
 }
 
 // 1 while work enqueued on the engine is still in flight, 0 when it is idle: a query, never a wait.  (The main stream is
-// the one asked: the last tree launch of a run waits for the last re-roots of the side stream, so an idle main stream
-// means an idle engine.)
+// the one asked: everything a run enqueues is on it — in side-stream mode the last tree launch of a run waits for the last
+// re-roots — so an idle main stream means an idle engine.)
 extern "C" int azh_engine_query(azh_engine *e)
 {
     if (!e)

@@ -94,6 +94,7 @@ SIGNATURES = {
     "azh_engine_set_evals": (ctypes.c_int, [_vp, _vp, _vp]),
     "azh_engine_backup": (ctypes.c_int, [_vp]),
     "azh_engine_run": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
+    "azh_engines_run": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int]),
     "azh_engine_run_arena": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     "azh_engine_sync": (ctypes.c_int, [_vp]),
     "azh_engine_set_visits": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -319,6 +320,12 @@ class Net:
 
 
 # ------------------------------------------------------------------ engine
+
+def run_engines(engines, net, iterations, dtype=DTYPE_BF16):
+    """engine.run for several engines of one GPU, their iterations enqueued in turn (azh_engines_run)."""
+    handles = (ctypes.c_void_p * len(engines))(*[e.h for e in engines])
+    check(load().azh_engines_run(handles, len(engines), net.h, dtype, iterations))
+
 
 class Engine:
     """Batched self-play search on the GPU (cpp/self_play_client.cpp's workers)."""

@@ -93,8 +93,13 @@ class SelfPlay:
         self.games = games
 
     def run(self, iterations):
-        # every engine enqueues its whole run on its own streams (the calls are asynchronous): the half-batches then
-        # advance independently on the GPU, one's tree phase and tower tail filled by the other's tower
+        # every engine's whole run is enqueued on its own stream (the calls are asynchronous): the half-batches then
+        # advance independently on the GPU, one's tree phase and tower tail filled by the other's tower.  The engines'
+        # iterations are enqueued in turn (azh_engines_run), so that the second half starts with the first launches
+        # enqueued and not a run's worth of host time later (AZH_ENQUEUE_SEQUENTIAL=1: engine after engine, rounds 4-5).
+        if len(self.engines) > 1 and os.environ.get("AZH_ENQUEUE_SEQUENTIAL", "0") in ("", "0"):
+            link.run_engines(self.engines, self.net, iterations, self.dtype)
+            return
         for e in self.engines:
             e.run(self.net, iterations, self.dtype)
 

@@ -556,8 +556,8 @@ def main():
                          "avg_launch_ms": launch_ms, "evals_per_launch": evals_per_launch,
                          "launches_timed": it, "launches_in_region": iters * args.streams, "flops_per_eval": flops},
             "tree_roofline": {"bound": "hbm", "kernels": "k_tree (backup + move-due mark + select + leaf-list compaction, one launch, four games per "
-                                         "workgroup, one beyond 8192 games) on the engine's stream; k_advance_list (re-roots) on a high-priority side "
-                                         "stream under the tower",
+                                         "workgroup, one beyond 8192 games) on the engine's stream; the queued moves (re-roots) are played by "
+                                         "the first workgroups of the tower launch",
                               "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS,
                               # what this chip delivers for the launch's own access pattern — dependent scattered 672-byte
                               # reads, one chain per wave (tools/microbench/random_chase.hip): 3.1 TB/s with 4096 chains in

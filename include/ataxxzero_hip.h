@@ -225,6 +225,9 @@ int azh_engine_backup(azh_engine *e);
 
 /* `iterations` full iterations with the built-in net, enqueued asynchronously */
 int azh_engine_run(azh_engine *e, azh_net *net, int dtype, int iterations);
+/* the same run for n engines of one GPU (half-batches: the reference's double buffer, cpp/self_play_client.cpp:593-600),
+ * their iterations enqueued in turn, so that all of them start with the first launches enqueued */
+int azh_engines_run(azh_engine *const *engines, int n, azh_net *net, int dtype, int iterations);
 /* arena (AZH_FLAG_TWO_NETS): net_a plays x in even slots and o in odd slots, net_b the
  * other way round (uai_ringmaster.py:241-247 queues every pairing both ways).  Per iteration the leaves whose mover is net_a and
  * those whose mover is net_b are evaluated by ONE launch of the 16-bit tower (each workgroup picks its weight set from the list
