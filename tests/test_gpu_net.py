@@ -183,6 +183,15 @@ def test_other_filter_counts(filters, blocks, n):
     ge.sync()
     st = ge.stats()
     assert st["plies"] > 40 * 5 and st["edge_overflow"] == 0
+    # ... and the device-resident loop with this width's f32 tower (whose launch also carries the loop's move-playing
+    # workgroups) stays the oracle's search bit for bit
+    from tests.test_gpu_engine import _oracle_follow, compare_all
+    oe, ge = orc.Engine(ocfg), link.Engine(link.Config(**{k: getattr(ocfg, k) for k, _ in orc.Config._fields_}))
+    ge.run(net, 150, link.DTYPE_F32)
+    _oracle_follow(oe, net, ocfg.blockers, 150)
+    ge.sync()
+    compare_all(oe, ge, range(40))
+    assert oe.stats()["plies"] > 40 * 5
     with pytest.raises(link.AzhError):
         link.Net(*model.random_init(1, 96, seed=1))   # only 64 / 128 / 256 are built
 
