@@ -1683,6 +1683,7 @@ static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream, co
 {
     typedef Geo<DT, NB, FT> G;
     static_assert(G::LDS_BYTES <= 160 * 1024, "tower image does not fit one CU's LDS");
+    static_assert(G::LDS_BYTES >= (int)sizeof(TreeLds), "the launch's move-playing workgroups use the tower's LDS as their scratch");
     static bool attr_set[MAX_DEVICES] = {};  // the attribute is per device: a process may drive several GPUs
     const int dev = current_device();
     if (dev < 0)
@@ -1705,6 +1706,7 @@ static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream, co
 template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &args, int max_n, hipStream_t stream,
                                                                const AdvanceHook &H = no_hook())
 {
+    static_assert(Geo2::LDS_BYTES >= (int)sizeof(TreeLds), "the launch's move-playing workgroups use the tower's LDS as their scratch");
     static bool attr_set[MAX_DEVICES] = {};
     const int dev = current_device();
     if (dev < 0)
