@@ -632,7 +632,7 @@ def test_two_half_batches_in_flight_match_their_oracles_at_bench_size():
     """bench.py's and the generator's default since round 4, at the size `value` is measured on: selfplay.SelfPlay(streams=2) =
     two engines of 2048 games, 400 sims/move, 12x128, level budget 48, sharing one packed weight set (the reference's double
     buffer, cpp/self_play_client.cpp:593-600; per game the loop of :419-473).  Both halves' runs are ENQUEUED before either
-    is waited for — four streams, the cross-stream kernel stop events, each half's tree launches squeezed under the other
+    is waited for — a stream each, their iterations enqueued in turn (azh_engines_run), each half's tree launches squeezed under the other
     half's tower — and each half is then compared with an oracle engine of its own: every game state, every arena word,
     every JSON line.  (The f32 tower is bit-identical wherever a board sits in a launch and whatever runs beside it.)"""
     seed, G, V = 4242, 4096, 400

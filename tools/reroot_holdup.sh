@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Rounds 3-5's loop only — since round 6 the queued moves ride in the tower launch; export AZH_REROOT_SIDE_STREAM=1 to trace the old loop.)
 # Does a re-root launch (k_advance_list, side stream) hold up the tree launch that waits for it?  It starts beside a tower
 # and the next k_tree of its engine waits for both: the hold-up is how far the re-root launch outlasts that tower.
 # rocprofv3 kernel trace of bench.py with ARGS (default: configs[3] = 8x128, f16, 800 sims/move as the headline, two
