@@ -1418,6 +1418,7 @@ struct RunLoop {
         const char *side_s = getenv("AZH_REROOT_SIDE_STREAM");
         side = side_s && atoi(side_s) != 0;
         hook.workers = e->adv_workers;
+        hook.at_head = 1;   // (decided per launch by the tower's launch functions: in front only where workgroups queue for slots)
         hook.P = e->P;
         e->unfetched_work = true;  // (every path that can finish a game goes through a re-root)
         launch_tree(false, 2, side ? e->ev_sel : nullptr);  // select + leaf list

@@ -602,13 +602,17 @@ __device__ inline void advance_game(const EngineParams &P, int g, TreeLds &L)
     }
 }
 
-// The queued moves of one search iteration, played by the first `workers` workgroups of the tower launch that follows the
+// The queued moves of one search iteration, played by `workers` workgroups of the tower launch (its first ones: at_head) that follows the
 // tree launch which queued them (mark_game): worker w takes the games adv_list[w], adv_list[w + workers], ... (one wave; the
 // workgroup's other waves return at once), the last worker to finish empties the queue.  `smem`: the workgroup's LDS (the
 // tower's image: not in use by a worker).  The tree launch behind the tower finds every move played — same stream, kernel
 // order — exactly as it did behind the side stream's k_advance_list.
 struct AdvanceHook {
     int workers;      // 0: the launch plays no moves (evaluations outside the device loop)
+    int at_head;      // 1: the workers are the launch's FIRST workgroups — a launch of more workgroups than the chip has slots,
+                      // whose last ones wait for earlier ones to retire; 0: its last workgroups — a launch that fits the chip at
+                      // once, where every workgroup starts at once anyway and workers in front would only push tiles onto CUs
+                      // that already hold one (set per launch by the tower's launch functions)
     EngineParams P;
 };
 

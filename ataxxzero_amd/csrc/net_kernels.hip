@@ -161,12 +161,16 @@ __device__ inline bool tower_prologue(const AdvanceHook &H, unsigned char *smem,
     wg = (int)blockIdx.x;
     if (H.workers == 0)
         return false;
-    if (wg < H.workers) {
+    // (a launch that fits the chip at once keeps its tiles in front: H.at_head = 0, the workers are its last workgroups)
+    const int tiles = (int)gridDim.x - H.workers;
+    const int worker = H.at_head ? wg : wg - tiles;
+    if (worker >= 0 && worker < H.workers) {
         if (threadIdx.x < WAVE)
-            advance_worker(H.P, smem, wg, H.workers);
+            advance_worker(H.P, smem, worker, H.workers);
         return true;
     }
-    wg -= H.workers;
+    if (H.at_head)
+        wg -= H.workers;
     return false;
 }
 
@@ -1678,6 +1682,23 @@ static const AdvanceHook &no_hook()
     return h;
 }
 
+// Where a launch of `tiles` tile workgroups puts its move-playing workgroups: in front when the launch has more workgroups than
+// the chip has slots for them (`per_cu` workgroups of this kernel per CU), behind the tiles when everything starts at once.
+static AdvanceHook place_workers(const AdvanceHook &H, int tiles, int per_cu)
+{
+    static int cus[MAX_DEVICES] = {};
+    AdvanceHook out = H;
+    if (H.workers == 0)
+        return out;
+    const int dev = current_device();
+    if (dev >= 0 && cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    out.at_head = tiles + H.workers > per_cu * (dev >= 0 ? cus[dev] : 256) ? 1 : 0;
+    return out;
+}
+
 template <int DT, int NB, int WPS, bool STAMP = false, int FT = F>
 static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream, const AdvanceHook &H = no_hook())
 {
@@ -1693,10 +1714,11 @@ static int launch_tower(const TowerArgs &args, int max_n, hipStream_t stream, co
                                     G::LDS_BYTES));
         attr_set[dev] = true;
     }
-    const int grid = (max_n + G::BOARDS - 1) / G::BOARDS + H.workers;
+    const int tiles = (max_n + G::BOARDS - 1) / G::BOARDS, grid = tiles + H.workers;
     if (grid <= 0)
         return 0;
-    hipLaunchKernelGGL((k_tower<DT, NB, WPS, STAMP, FT>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES, stream, args, H);
+    hipLaunchKernelGGL((k_tower<DT, NB, WPS, STAMP, FT>), dim3(grid), dim3(G::NTHR), G::LDS_BYTES, stream, args,
+                       place_workers(H, tiles, WPS * 256 / G::NTHR > 0 ? WPS * 256 / G::NTHR : 1));
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -1716,10 +1738,10 @@ template <int DT, bool STAMP = false> static int launch_tower2(const TowerArgs &
                                     Geo2::LDS_BYTES));
         attr_set[dev] = true;
     }
-    const int grid = (max_n + Geo2::BOARDS - 1) / Geo2::BOARDS + H.workers;
+    const int tiles = (max_n + Geo2::BOARDS - 1) / Geo2::BOARDS, grid = tiles + H.workers;
     if (grid <= 0)
         return 0;
-    hipLaunchKernelGGL((k_tower2<DT, STAMP>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args, H);
+    hipLaunchKernelGGL((k_tower2<DT, STAMP>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args, place_workers(H, tiles, 2));
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -1737,7 +1759,8 @@ template <int DT> static int launch_tower2_thin(const TowerArgs &args, int max_n
     }
     if (max_n + H.workers <= 0)
         return 0;
-    hipLaunchKernelGGL((k_tower2_thin<DT>), dim3(max_n + H.workers), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args, H);
+    hipLaunchKernelGGL((k_tower2_thin<DT>), dim3(max_n + H.workers), dim3(NTHREADS), Geo2::LDS_BYTES, stream, args,
+                       place_workers(H, max_n, 2));
     AZH_HIP(hipGetLastError());
     return 0;
 }
@@ -1887,8 +1910,9 @@ int azh_net_launch_pair(azh_net *net_a, azh_net *net_b, int dtype, const unsigne
         attr_set[dev][k] = true;
     }
     // ceil(nA / B) + ceil(nB / B) <= (nA + nB) / B + 2 workgroups of B boards (B = 3, or 1 for thin batches)
-    const AdvanceHook &H = advance_hook ? *static_cast<const AdvanceHook *>(advance_hook) : no_hook();
-    const int grid = max_n / (thin ? Geo2Thin::BOARDS : Geo2::BOARDS) + 2 + H.workers;
+    const int tiles = max_n / (thin ? Geo2Thin::BOARDS : Geo2::BOARDS) + 2;
+    const AdvanceHook H = place_workers(advance_hook ? *static_cast<const AdvanceHook *>(advance_hook) : no_hook(), tiles, 2);
+    const int grid = tiles + H.workers;
     switch (k) {
     case 0: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_BF16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b, H); break;
     case 1: hipLaunchKernelGGL((k_tower2_pair<AZH_DTYPE_F16>), dim3(grid), dim3(NTHREADS), Geo2::LDS_BYTES, stream, a, b, H); break;
