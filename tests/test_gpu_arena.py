@@ -148,34 +148,39 @@ def _match_in_lock_step(m, oe, net_a, net_b, dtype, thin, rounds, round_iters, s
     blockers = oe.cfg.blockers
     lines, switched = [], None
     followed = 0
-    m.run(round_iters)
+    thin_from = None                                # first chunk of iterations that was enqueued after the switch
+    m.run(round_iters)                              # chunk 0; round r enqueues chunk r + 1 and follows chunk r
     enqueued = round_iters
+
+    def follow(chunk):
+        nonlocal followed
+        thin_now = thin or (follow_thin_after_switch and thin_from is not None and chunk >= thin_from)
+        _oracle_follow(oe, net_a, blockers, enqueued - followed, dtype=dtype, thin=thin_now, net_b=net_b)
+        followed = enqueued
+
     for r in range(rounds):
-        m.fetch()                                   # waits for the iterations enqueued so far
-        thin_now = thin or (follow_thin_after_switch and switched is not None)
+        m.fetch()                                   # waits for the iterations enqueued so far (chunks 0 .. r)
         if r in sync_rounds:                        # (nothing in flight here: states and arenas can be read)
-            _oracle_follow(oe, net_a, blockers, enqueued - followed, dtype=dtype, thin=thin_now, net_b=net_b)
-            followed = enqueued
+            follow(r)
             compare_all(oe, m.engine, range(oe.G))
-        m.run(round_iters)                          # the next round runs while the finished games are parsed and scored
+        m.run(round_iters)                          # chunk r + 1 runs while the finished games are parsed and scored
         if followed < enqueued:
-            _oracle_follow(oe, net_a, blockers, enqueued - followed, dtype=dtype, thin=thin_now, net_b=net_b)
-            followed = enqueued
+            follow(r)
         enqueued += round_iters
         o_chunk = sorted(oe.pop_games(partial=True), key=lambda g: g["uid"])
         was_thin = m.thin
         g_chunk = m.drain()
         if m.thin and not was_thin:
             switched = r
+            thin_from = r + 2                       # (chunk r + 1 was enqueued before this drain: still the 3-board kernel)
         assert len(g_chunk) == len(o_chunk), r
         for g, rec in zip(g_chunk, o_chunk):
             opening = g["opening"]
             assert g["uid"] == rec["uid"] and g["moves"][len(opening):] == rec["entry"]["moves"], r
             assert g["boards"] == rec["entry"]["boards"] and g["result"] == rec["entry"]["result"], r
         lines += g_chunk
-    # the round still in flight: the oracle follows it, and its games are the last chunk
-    thin_now = thin or (follow_thin_after_switch and switched is not None)
-    _oracle_follow(oe, net_a, blockers, enqueued - followed, dtype=dtype, thin=thin_now, net_b=net_b)
+    # the chunk still in flight: the oracle follows it, and its games are the last ones
+    follow(rounds)
     m.fetch()
     o_chunk = sorted(oe.pop_games(partial=True), key=lambda g: g["uid"])
     g_chunk = m.drain()
@@ -184,25 +189,29 @@ def _match_in_lock_step(m, oe, net_a, net_b, dtype, thin, rounds, round_iters, s
     return lines + g_chunk, switched
 
 
-def test_arena_device_loop_matches_oracle_at_config5_size():
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_arena_device_loop_matches_oracle_at_config5_size(dtype):
     """BASELINE configs[4] as bench.py's config5 leg and uai_ringmaster.py's drop-in run it — azh_engine_run_arena: 1000 games
     in flight, 100 visits per move from a fresh tree, two 12x128 nets, one leaf list per net, a fixed cohort under the game
     limit (slots go idle), arena.Match's fetch -> run -> drain order and its switch to thin batches once at most 512 games
     are left — against the oracle's arena mode (engine.py:474-530, uai_ringmaster.py:221-265) whose leaves go to net A or
     net B by the side to move: every game of every round, every state and arena word at four sync points, one of them after
-    the switch.  f32 towers (bit-identical wherever a board sits; the switch changes no kernel there), and the match starts
-    from random openings of 170 plies (uai_ringmaster.get_opening) so that games end, slots idle and the batch thins
-    within a few thousand iterations instead of forty thousand."""
+    the switch.  f32: one launch per net, bit-identical wherever a board sits.  f16 — the leg's own dtype: both nets' lists in
+    ONE launch of k_tower2_pair, three boards per workgroup until the switch, one board per workgroup after it; the oracle's
+    leaves go through azh_net_forward (before the switch) / azh_net_forward_thin (after it) list by list in game order, which
+    puts every board in the slot it has in the pair launch (each list starts at a workgroup of its own).  The match starts from
+    random openings of 170 plies (uai_ringmaster.get_opening) so that games end, slots idle and the batch thins within a
+    few thousand iterations instead of forty thousand."""
     G, V, seed = 1000, 100, 20260101
     wa, wb = model.random_init(12, 128, seed=1), model.random_init(12, 128, seed=2)
-    m = arena.Match(wa, wb, V, games=G, dtype="f32", seed=seed, opening_depth=170)
+    m = arena.Match(wa, wb, V, games=G, dtype=dtype, seed=seed, opening_depth=170)
     oe = _arena_oracle(m, G, V, seed)
     oe.set_positions(np.repeat(m.opening_boards, 2, axis=0), np.full(G, 170, dtype=np.int32))
     m.set_game_limit(G)
     oe.set_game_limit(G)
     rounds = 44
-    lines, switched = _match_in_lock_step(m, oe, m.net_a, m.net_b, link.DTYPE_F32, False, rounds, 50,
-                                          sync_rounds=(1, 14, 29, rounds - 1))
+    lines, switched = _match_in_lock_step(m, oe, m.net_a, m.net_b, link.DTYPES[dtype], False, rounds, 50,
+                                          sync_rounds=(1, 14, 29, rounds - 1), follow_thin_after_switch=True)
     compare_all(oe, m.engine, range(G))
     so, sg = oe.stats(), m.engine.stats()
     for k in so:

@@ -628,16 +628,20 @@ def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, bl
         assert so["reroot_nodes"] > so["plies"]  # subtrees are really kept across moves
 
 
-def test_two_half_batches_in_flight_match_their_oracles_at_bench_size():
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_two_half_batches_in_flight_match_their_oracles_at_bench_size(dtype):
     """bench.py's and the generator's default since round 4, at the size `value` is measured on: selfplay.SelfPlay(streams=2) =
     two engines of 2048 games, 400 sims/move, 12x128, level budget 48, sharing one packed weight set (the reference's double
     buffer, cpp/self_play_client.cpp:593-600; per game the loop of :419-473).  Both halves' runs are ENQUEUED before either
     is waited for — a stream each, their iterations enqueued in turn (azh_engines_run), each half's tree launches squeezed under the other
     half's tower — and each half is then compared with an oracle engine of its own: every game state, every arena word,
-    every JSON line.  (The f32 tower is bit-identical wherever a board sits in a launch and whatever runs beside it.)"""
+    every JSON line.  (The f32 tower is bit-identical wherever a board sits in a launch and whatever runs beside it; bf16 —
+    the dtype and the kernel the headline is measured with — is followed with the oracle's leaves handed to the same
+    3-board kernel in leaf-list order, i.e. in the slots they have in the loop's launches.)"""
     seed, G, V = 4242, 4096, 400
+    dt = link.DTYPES[dtype]
     conv, bn = model.random_init(12, 128, seed=7)
-    sp = selfplay.SelfPlay(conv, bn, games=G, visits=V, dtype="f32", seed=seed, streams=2, select_budget=48)
+    sp = selfplay.SelfPlay(conv, bn, games=G, visits=V, dtype=dtype, seed=seed, streams=2, select_budget=48)
     oes = [orc.Engine(orc.make_config(G // 2, V, seed=seed + 1000003 * i, select_budget=48)) for i in range(2)]
     for oe, ge in zip(oes, sp.engines):
         for n, _ in orc.Config._fields_:
@@ -647,7 +651,7 @@ def test_two_half_batches_in_flight_match_their_oracles_at_bench_size():
     def advance(iterations):
         sp.run(iterations)                       # both halves enqueued, neither synced
         for oe in oes:
-            _oracle_follow(oe, sp.net, blockers, iterations)
+            _oracle_follow(oe, sp.net, blockers, iterations, dtype=dt)
         sp.sync()
 
     # bench.py's spread: games are taken off ply 0 at 16 sims/move first, then the trees regrow at full sims
@@ -735,6 +739,41 @@ def test_thin_batch_device_loop_in_16_bits_matches_oracle_bit_for_bit(dtype):
             assert so[k] == sg[k], (k, so[k], sg[k])
         assert n_lines > 20 and so["dropped"] > 0 and so["plies"] > 10 * games
         ge.close()
+
+
+@pytest.mark.parametrize("dtype,streams", [("bf16", 1), ("f16", 1), ("bf16", 2)])
+def test_three_board_16_bit_tower_in_the_device_loop_matches_oracle_bit_for_bit(dtype, streams):
+    """The loop as bench.py and the generator run it by default — the 16-bit tower with three boards per workgroup — pinned to
+    the oracle bit for bit.  A board's last bits depend on its slot in its workgroup, and the slot on its place in the
+    iteration's leaf list; but the leaf list is the games that need an evaluation in ascending order, so the oracle's leaves
+    handed to azh_net_forward in that order sit in the same slots of the same kernel (a board's cells are its own columns of
+    the contraction: what its neighbours in the workgroup hold does not matter).  `streams` = 2: two half-batches in flight,
+    their runs enqueued in turn (azh_engines_run), each followed by an oracle of its own."""
+    dt = link.DTYPES[dtype]
+    seed, G, V = 515, 1536 * streams, 40
+    conv, bn = model.random_init(4, 128, seed=19)
+    sp = selfplay.SelfPlay(conv, bn, games=G, visits=V, dtype=dtype, seed=seed, streams=streams, select_budget=8, max_plies=110)
+    oes = [orc.Engine(orc.make_config(G // streams, V, seed=seed + 1000003 * i, select_budget=8, max_plies=110)) for i in range(streams)]
+    assert all(e.G > link.THIN_MAX_GAMES for e in sp.engines)      # the 3-board kernel, by the engines' size
+    n_lines = 0
+    for c in range(5):
+        sp.run(220)
+        for oe in oes:
+            _oracle_follow(oe, sp.net, oe.cfg.blockers, 220, dtype=dt)
+        sp.sync()
+        for oe, ge in zip(oes, sp.engines):
+            compare_all(oe, ge, range(0, ge.G, 3))
+            o_chunk = sorted(oe.pop_games(), key=lambda r: r["uid"])
+            g_chunk = ge.drain_json()
+            assert [json.loads(l) for l in g_chunk] == [r["entry"] for r in o_chunk], c
+            n_lines += len(g_chunk)
+    for oe, ge in zip(oes, sp.engines):
+        so, sg = oe.stats(), ge.stats()
+        for k in so:
+            assert so[k] == sg[k], (k, so[k], sg[k])
+        assert sg["parked"] > 0 and so["plies"] > 10 * ge.G
+    assert n_lines > 50
+    sp.close()
 
 
 def test_uid_ordered_emission_is_an_unbiased_prefix():
