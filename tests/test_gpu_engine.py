@@ -570,22 +570,24 @@ def _oracle_follow(oe, net, blockers, iterations, dtype=link.DTYPE_F32, thin=Fal
         oe.backup(logits, values)
 
 
-@pytest.mark.parametrize("name,games,visits,blocks,max_plies,budget,chunks,chunk", [
-    ("turnover", 512, 12, 2, 90, 6, 12, 250),        # many plies: games finish, are cut at max_plies, slots restart
-    ("budget48", 512, 100, 2, 400, 48, 6, 100),      # the bench's level budget
-    ("C2-shape", 192, 200, 12, 400, 48, 4, 150),     # BASELINE configs[1]: 12x128 net, 200 sims/move
-    ("C4-shape", 48, 800, 8, 400, 48, 4, 450),       # BASELINE configs[3]: 8x128 net, 800 sims/move, node_cap 808
-    ("bench-size", 4096, 400, 12, 400, 48, 3, 150),  # bench.py's workload: 4096 games, 400 sims/move, 12x128
-    ("two-rounds", 8203, 8, 1, 60, 6, 2, 40),        # more games than resident waves (8192): one game per workgroup,
-                                                     # a need-bit mask with a ragged last word
-    ("turnover-side-stream", 512, 12, 2, 90, 6, 12, 250),   # rounds 3-5's loop (AZH_REROOT_SIDE_STREAM=1): the queued moves as
-                                                            # k_advance_list on a side stream behind events
+@pytest.mark.parametrize("name,games,visits,blocks,max_plies,budget,chunks,chunk,dtype", [
+    ("turnover", 512, 12, 2, 90, 6, 12, 250, "f32"),        # many plies: games finish, are cut at max_plies, slots restart
+    ("budget48", 512, 100, 2, 400, 48, 6, 100, "f32"),      # the bench's level budget
+    ("C2-shape", 768, 200, 12, 400, 48, 4, 150, "bf16"),    # BASELINE configs[1]: 12x128 net, 200 sims/move, bf16 (3-board tower)
+    ("C4-shape", 576, 800, 8, 400, 48, 4, 450, "f16"),      # BASELINE configs[3]: 8x128 net, 800 sims/move, f16, node_cap 808
+    ("bench-size", 4096, 400, 12, 400, 48, 3, 150, "bf16"), # bench.py's workload as one batch: 4096 games, 400 sims/move, 12x128, bf16
+    ("two-rounds", 8203, 8, 1, 60, 6, 2, 40, "f32"),        # more games than resident waves (8192): one game per workgroup,
+                                                            # a need-bit mask with a ragged last word
+    ("turnover-side-stream", 512, 12, 2, 90, 6, 12, 250, "f32"),   # rounds 3-5's loop (AZH_REROOT_SIDE_STREAM=1): the queued moves
+                                                                   # as k_advance_list on a side stream behind events
 ])
-def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, blocks, max_plies, budget, chunks, chunk, monkeypatch):
+def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, blocks, max_plies, budget, chunks, chunk, dtype, monkeypatch):
     """The loop bench.py and the CLI run — azh_engine_run: fused k_tree, the queued moves played by the first workgroups of
     the tower launch, parked descents — against the oracle, iteration for iteration: every game state, every arena word and
     every JSON line.  (The step-wise API the other lock-step tests drive shares the device functions but not the launch
-    structure.)"""
+    structure.)  The two BASELINE shapes run in their own dtype with the three-board tower (more than 512 slots): the oracle's
+    leaves are evaluated by the same kernel in leaf-list order, which gives every board the slot it has in the loop."""
+    dt = link.DTYPES[dtype]
     if name.endswith("side-stream"):
         monkeypatch.setenv("AZH_REROOT_SIDE_STREAM", "1")
         name = name[:-len("-side-stream")]
@@ -599,13 +601,13 @@ def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, bl
         # bench.py's spread: games are taken off ply 0 at 16 sims/move first, then the trees regrow at full sims
         for e in (oe, ge):
             e.set_visits(16)
-        ge.run(net, 500, link.DTYPE_F32)
-        _oracle_follow(oe, net, oe.cfg.blockers, 500)
+        ge.run(net, 500, dt)
+        _oracle_follow(oe, net, oe.cfg.blockers, 500, dtype=dt)
         for e in (oe, ge):
             e.set_visits(visits)
     for c in range(chunks):
-        ge.run(net, chunk, link.DTYPE_F32)
-        _oracle_follow(oe, net, oe.cfg.blockers, chunk)
+        ge.run(net, chunk, dt)
+        _oracle_follow(oe, net, oe.cfg.blockers, chunk, dtype=dt)
         ge.sync()
         # (beyond 5000 games every fifth game and both ends: the tree dumps are one copy per array and game)
         sample = range(games) if games <= 5000 else sorted(set(range(0, games, 5)) | set(range(64)) | set(range(games - 64, games)))
