@@ -576,6 +576,8 @@ def _oracle_follow(oe, net, blockers, iterations, dtype=link.DTYPE_F32, thin=Fal
     ("C2-shape", 768, 200, 12, 400, 48, 4, 150, "bf16"),    # BASELINE configs[1]: 12x128 net, 200 sims/move, bf16 (3-board tower)
     ("C4-shape", 576, 800, 8, 400, 48, 4, 450, "f16"),      # BASELINE configs[3]: 8x128 net, 800 sims/move, f16, node_cap 808
     ("bench-size", 4096, 400, 12, 400, 48, 3, 150, "bf16"), # bench.py's workload as one batch: 4096 games, 400 sims/move, 12x128, bf16
+    ("C2-full", 4096, 200, 12, 400, 48, 3, 150, "bf16"),    # BASELINE configs[1] at its full size: 4096 games, 200 sims/move, bf16
+    ("C4-full", 4096, 800, 8, 400, 48, 2, 300, "f16"),      # BASELINE configs[3] at its full size: 4096 games, 800 sims/move, 8x128, f16
     ("two-rounds", 8203, 8, 1, 60, 6, 2, 40, "f32"),        # more games than resident waves (8192): one game per workgroup,
                                                             # a need-bit mask with a ragged last word
     ("turnover-side-stream", 512, 12, 2, 90, 6, 12, 250, "f32"),   # rounds 3-5's loop (AZH_REROOT_SIDE_STREAM=1): the queued moves
@@ -597,7 +599,7 @@ def test_device_resident_loop_matches_oracle_bit_for_bit(name, games, visits, bl
     assert ge.node_cap == visits + 8
     g_lines = []
     parked = 0
-    if name == "bench-size":
+    if name in ("bench-size", "C2-full", "C4-full"):
         # bench.py's spread: games are taken off ply 0 at 16 sims/move first, then the trees regrow at full sims
         for e in (oe, ge):
             e.set_visits(16)
