@@ -745,8 +745,9 @@ def test_thin_batch_device_loop_in_16_bits_matches_oracle_bit_for_bit(dtype):
         ge.close()
 
 
-@pytest.mark.parametrize("dtype,streams", [("bf16", 1), ("f16", 1), ("bf16", 2)])
-def test_three_board_16_bit_tower_in_the_device_loop_matches_oracle_bit_for_bit(dtype, streams):
+@pytest.mark.parametrize("dtype,streams,flags", [("bf16", 1, 0), ("f16", 1, 0), ("bf16", 2, 0),
+                                                 ("bf16", 2, link.FLAG_EVAL_CACHE)])   # the last: the generator CLI's defaults
+def test_three_board_16_bit_tower_in_the_device_loop_matches_oracle_bit_for_bit(dtype, streams, flags):
     """The loop as bench.py and the generator run it by default — the 16-bit tower with three boards per workgroup — pinned to
     the oracle bit for bit.  A board's last bits depend on its slot in its workgroup, and the slot on its place in the
     iteration's leaf list; but the leaf list is the games that need an evaluation in ascending order, so the oracle's leaves
@@ -756,8 +757,10 @@ def test_three_board_16_bit_tower_in_the_device_loop_matches_oracle_bit_for_bit(
     dt = link.DTYPES[dtype]
     seed, G, V = 515, 1536 * streams, 40
     conv, bn = model.random_init(4, 128, seed=19)
-    sp = selfplay.SelfPlay(conv, bn, games=G, visits=V, dtype=dtype, seed=seed, streams=streams, select_budget=8, max_plies=110)
-    oes = [orc.Engine(orc.make_config(G // streams, V, seed=seed + 1000003 * i, select_budget=8, max_plies=110)) for i in range(streams)]
+    sp = selfplay.SelfPlay(conv, bn, games=G, visits=V, dtype=dtype, seed=seed, streams=streams, select_budget=8, max_plies=110,
+                           flags=flags)
+    oes = [orc.Engine(orc.make_config(G // streams, V, seed=seed + 1000003 * i, select_budget=8, max_plies=110, flags=flags))
+           for i in range(streams)]
     assert all(e.G > link.THIN_MAX_GAMES for e in sp.engines)      # the 3-board kernel, by the engines' size
     n_lines = 0
     for c in range(5):
@@ -775,7 +778,7 @@ def test_three_board_16_bit_tower_in_the_device_loop_matches_oracle_bit_for_bit(
         so, sg = oe.stats(), ge.stats()
         for k in so:
             assert so[k] == sg[k], (k, so[k], sg[k])
-        assert sg["parked"] > 0 and so["plies"] > 10 * ge.G
+        assert sg["parked"] > 0 and so["plies"] > 10 * ge.G and (sg["cache_hits"] > 0) == bool(flags)
     assert n_lines > 50
     sp.close()
 
