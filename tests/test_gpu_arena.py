@@ -189,7 +189,7 @@ def _match_in_lock_step(m, oe, net_a, net_b, dtype, thin, rounds, round_iters, s
     return lines + g_chunk, switched
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("dtype", ["f16"])   # ("f32" passes too — 38 s: one launch per net; that path is held by the pair == two-launches test)
 def test_arena_device_loop_matches_oracle_at_config5_size(dtype):
     """BASELINE configs[4] as bench.py's config5 leg and uai_ringmaster.py's drop-in run it — azh_engine_run_arena: 1000 games
     in flight, 100 visits per move from a fresh tree, two 12x128 nets, one leaf list per net, a fixed cohort under the game
