@@ -1061,6 +1061,7 @@ struct azh_engine {
     u64 *h_head = nullptr;
     u32 *h_stage = nullptr;
     size_t h_stage_words = 0;
+    std::vector<u32 *> h_stage_retired;
     bool selected = false;
     bool arena_lists = false;  // run_arena: one leaf list per net
     bool stamp_next = false;   // azh_engine_tree_stamps: the next fused tree launch of the loop is the stamped instantiation
@@ -1211,6 +1212,8 @@ extern "C" void azh_engine_destroy(azh_engine *e)
         (void)hipHostFree(e->h_head);
     if (e->h_stage)
         (void)hipHostFree(e->h_stage);
+    for (u32 *q : e->h_stage_retired)
+        (void)hipHostFree(q);
     if (e->ev_sel)
         (void)hipEventDestroy(e->ev_sel);
     if (e->ev_adv)
@@ -1790,8 +1793,10 @@ static int fetch_records(azh_engine *e)
             size_t want = (size_t)1 << 20;
             while (want < (size_t)head)
                 want <<= 1;
+            // (the outgrown buffer is kept until the engine is destroyed: freeing pinned memory waits for the whole device,
+            // i.e. for the other half-batch's run)
             if (e->h_stage)
-                (void)hipHostFree(e->h_stage);
+                e->h_stage_retired.push_back(e->h_stage);
             e->h_stage = nullptr;
             e->h_stage_words = 0;
             AZH_HIP(hipHostMalloc((void **)&e->h_stage, want * 4));
