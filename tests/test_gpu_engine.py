@@ -416,34 +416,39 @@ def test_one_random_move_variant_matches_oracle():
         assert replay_game_entry(entry, orc.START_FEN_SELFPLAY) == entry["result"]
 
 
-def test_symmetry_averaging_flag_in_the_device_loop_equals_host_evaluated_search():
+@pytest.mark.parametrize("dtype,games", [("f32", 9), ("bf16", 96)])
+def test_symmetry_averaging_flag_in_the_device_loop_equals_host_evaluated_search(dtype, games):
     # AZH_FLAG_SYMMETRY_AVG: every evaluation of the device loop is nn_evals.evaluate; the same search
-    # driven from the host with Net.forward_sym must build bit-identical trees (f32 tower on both sides)
+    # driven from the host with Net.forward_sym must build bit-identical trees — f32, and bf16 with the three-board tower
+    # (96 games x 8 images: the leaf list in game order puts every virtual board in the slot it has in the loop's launch)
+    dt = link.DTYPES[dtype]
     conv, bn = model.random_init(1, 128, seed=31)
     net = link.Net(conv, bn)
-    base = orc.make_config(9, 12, seed=4, max_plies=80, flags=link.FLAG_SYMMETRY_AVG)
+    base = orc.make_config(games, 12, seed=4, max_plies=80, flags=link.FLAG_SYMMETRY_AVG)
     mk = lambda: link.Engine(link.Config(**{n: getattr(base, n) for n, _ in orc.Config._fields_}))
     dev, host = mk(), mk()
+    if dtype != "f32":
+        dev.set_thin_batches(0)          # (azh_net_forward_sym runs the three-board kernel)
     iters = 90
-    dev.run(net, iters, link.DTYPE_F32)
+    dev.run(net, iters, dt)
     dev.sync()
     for _ in range(iters):
         host.select()
         need, lb = host.leaves()
-        logits = np.zeros((9, 833), np.float32)
-        values = np.zeros(9, np.float32)
+        logits = np.zeros((games, 833), np.float32)
+        values = np.zeros(games, np.float32)
         idx = np.nonzero(need)[0]
         if len(idx):
-            p, v = net.forward_sym(lb[idx], base.blockers, link.DTYPE_F32)
+            p, v = net.forward_sym(lb[idx], base.blockers, dt)
             logits[idx] = p.reshape(len(idx), 833)
             values[idx] = v.reshape(-1)
         host.set_evals(logits, values)
         host.backup()
-    for g in range(9):
+    for g in range(games):
         assert dev.game_state(g).as_tuple()[:6] == host.game_state(g).as_tuple()[:6]
         for a, b in zip(dev.tree(g), host.tree(g)):
             assert a.shape == b.shape and (a == b).all()
-    assert dev.stats()["plies"] == host.stats()["plies"] > 9
+    assert dev.stats()["plies"] == host.stats()["plies"] > games
 
 
 def test_parked_descents_match_oracle_and_leave_every_game_unchanged():
